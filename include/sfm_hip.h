@@ -1,0 +1,153 @@
+/* sfm_hip.h — C-ABI of libsfm_hip.so: the MI355X (gfx950) back end for the nonlinear-refinement
+ * hot path of willSapgreen/structure-from-motion.
+ *
+ * The reference is pure Python and has no FFI layer; its boundary for this path is the public
+ * method surface of three classes.  Every entry point below names the reference interface it
+ * replaces (file:line relative to the reference repo).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions (identical to the reference): float64 everywhere; rot = R (3x3 row-major),
+ * loc = C (camera centre); world->camera p = R^T (X - C); quaternion [qw,qx,qy,qz]; a camera
+ * parameter block is 7 doubles [Cx,Cy,Cz,qw,qx,qy,qz] (ba_processor.py:285-288); 3D points are
+ * homogeneous columns; 2D points are pixel columns [u,v,1].
+ *
+ * Unless a function says "device", all pointers are HOST memory borrowed for the duration of the
+ * call; outputs are caller-allocated.  Calls are blocking (they synchronise the library stream)
+ * except sfm_ba_iterate / sfm_ba_linearize_reduce / sfm_ba_solve_update, which only enqueue.
+ * No exception crosses the boundary: every function returns SFM_OK (0) or a negative status;
+ * sfm_last_error() returns a message for the calling thread's last failure.
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------------- */
+#define SFM_OK               0
+#define SFM_E_SHAPE         -1   /* bad sizes -> ValueError (campose_processor.py:353-357, triangulation_processor.py:65-74) */
+#define SFM_E_BAD_ROTATION  -2   /* verify_rotation_mat failed -> ValueError (utils.py:43-45, 93-95) */
+#define SFM_E_QW_ZERO       -3   /* |qw| < 1e-6 -> ValueError (utils.py:49-51) */
+#define SFM_E_SQRT_DOMAIN   -4   /* 1 + tr R < 0 -> math.sqrt ValueError (utils.py:47) */
+#define SFM_E_HIP           -5   /* HIP runtime error */
+#define SFM_E_NO_DEVICE     -6   /* no gfx950 device visible */
+#define SFM_E_HANDLE        -7   /* null / destroyed problem handle */
+
+/* ---- quirk bits; the reference's behaviour = SFM_QUIRKS_REFERENCE ------ */
+#define SFM_Q1_PNP_ROW_OVERLAP  1  /* campose_processor.py:404-405: rows stored at [pt:pt+2] */
+#define SFM_Q2_LOC_JAC_SIGN     2  /* campose_processor.py:802-804: sign of the v-row of d/dC */
+#define SFM_QUIRKS_REFERENCE    3
+
+/* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
+#define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, pair kernel otherwise */
+#define SFM_SCHUR_PAIRS   1  /* per-point camera-pair kernel (f64 atomics) */
+#define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over zero-filled LDS tiles */
+
+#define SFM_OPT_SCHUR        1
+#define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
+
+/* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */
+#define SFM_K_PREP       0
+#define SFM_K_LINEARIZE  1
+#define SFM_K_SCHUR      2
+#define SFM_K_SOLVE      3
+#define SFM_K_BACKSUB    4
+#define SFM_K_COUNT      5
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int sfm_version(void);
+/* Select the HIP device this process drives (one process per GPU) and create the library stream. */
+int sfm_init(int device);
+int sfm_shutdown(void);
+/* Run all subsequent work on an existing HIP stream (hipStream_t as void*), e.g. torch's current
+ * stream, so RCCL collectives issued by the host framework order correctly.  NULL = own stream. */
+int sfm_set_stream(void* hip_stream);
+int sfm_synchronize(void);
+const char* sfm_last_error(void);
+
+/* ---- unit-level helpers (parity hooks; batched) ------------------------------------------------ */
+/* utils.convert_quaternion_to_rotation (utils.py:64-97).  status[i] = SFM_OK / SFM_E_BAD_ROTATION. */
+int sfm_quat_to_rot(int n, const double* q /*[n][4]*/, double* R /*[n][9]*/, int* status /*[n]*/);
+/* utils.convert_rotation_to_quaternion (utils.py:28-60). */
+int sfm_rot_to_quat(int n, const double* R /*[n][9]*/, double* q /*[n][4]*/, int* status /*[n]*/);
+/* CamposeProcessor.construct_jacobian_matrix(rot, loc, pt_3d) -> (2,7) (campose_processor.py:462-482). */
+int sfm_jac_cam(int n, const double* R /*[n][9]*/, const double* C /*[n][3]*/, const double* X /*[n][4]*/,
+                int quirks, double* Jp /*[n][2][7]*/, int* status /*[n]*/);
+/* TriangulationProcessor.construct_jacobian_matrix(tri_3d_pt, projs, num_views) -> (2*num_views,3)
+ * (triangulation_processor.py:237-271). */
+int sfm_jac_pt(int n, int n_views, const double* projs /*[n][n_views][3][4]*/, const double* X /*[n][4]*/,
+               double* Jx /*[n][2*n_views][3]*/);
+
+/* ---- TriangulationProcessor.nonlinear_triangulate (triangulation_processor.py:160-234) --------- */
+/* One thread per point, all iterations in registers.  Row W of X is carried through unchanged. */
+int sfm_tri_nonlinear(int m, int n_views, const double* projs /*[n_views][3][4]*/,
+                      const double* uv /*[n_views][2][m]*/, const double* X_in /*[4][m]*/,
+                      double lambda, int iters, double* X_out /*[4][m]*/);
+
+/* ---- CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459) ----------- */
+int sfm_pnp_nonlinear(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/,
+                      const double K[9], const double R0[9], const double C0[3],
+                      double lambda, int iters, int quirks, double R_out[9], double C_out[3]);
+/* Independent views in one launch (one workgroup per view); view v owns columns
+ * [offsets[v], offsets[v+1]) of uv_pix / X.  status[v] per view. */
+int sfm_pnp_nonlinear_batch(int n_views, const int* offsets /*[n_views+1]*/, int total,
+                            const double* uv_pix /*[3][total]*/, const double* X /*[4][total]*/,
+                            const double* K /*[n_views][9]*/, const double* R0 /*[n_views][9]*/,
+                            const double* C0 /*[n_views][3]*/, double lambda, int iters, int quirks,
+                            double* R_out /*[n_views][9]*/, double* C_out /*[n_views][3]*/,
+                            int* status /*[n_views]*/);
+
+/* ---- BaProcessor.__execute_bundle_adjustment (ba_processor.py:274-439) ------------------------- */
+/* Observations are sorted by (point, camera) — the reference's loop order (ba_processor.py:304-306)
+ * — and given as a CSR over points: observation o in [pt_ptr[p], pt_ptr[p+1]) belongs to point p and
+ * camera cam_idx[o]; uv_norm[0][o], uv_norm[1][o] = inv(K)[u,v,1]^T / z (ba_processor.py:339-342). */
+int sfm_ba_solve(int V, int N, int64_t M, const int* pt_ptr /*[N+1]*/, const int* cam_idx /*[M]*/,
+                 const double* uv_norm /*[2][M]*/, double* cams /*[V][7] in/out*/,
+                 double* pts /*[3][N] in/out*/, double lambda, int iters, int quirks);
+
+/* Device-resident problem: upload once, iterate many times (what bench.py times). */
+typedef struct sfm_ba_problem sfm_ba_problem;
+int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx,
+                  const double* uv_norm, sfm_ba_problem** out);
+int sfm_ba_destroy(sfm_ba_problem* p);
+int sfm_ba_set_option(sfm_ba_problem* p, int option, int value);
+int sfm_ba_set_state(sfm_ba_problem* p, const double* cams /*[V][7]*/, const double* pts /*[3][N]*/);
+/* Enqueue `iters` damped Gauss-Newton iterations (ba_processor.py:297-406) on the library stream. */
+int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks);
+/* Synchronise, copy the state back, and report the first device-side failure (bad rotation ...). */
+int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
+/* Accumulated device time of one kernel class since the last reset (needs SFM_OPT_TIMING = 1);
+ * synchronises.  *launches may be NULL. */
+int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches);
+int sfm_ba_reset_timing(sfm_ba_problem* p);
+
+/* Multi-GPU split of one iteration (points sharded by rank, cameras replicated):
+ *   sfm_ba_linearize_reduce : this rank's partial reduced system [S (P x P, P = 7V padded to
+ *                             sfm_ba_reduced_ld) | rhs (P)] -> the reduced buffer (device)
+ *   <caller all-reduces (SUM, double) the reduced buffer across ranks, e.g. RCCL via torch.distributed>
+ *   sfm_ba_solve_update     : + lambda I, factor, solve, update cameras, back-substitute own points
+ * sfm_ba_iterate == these two back to back on one rank. */
+int sfm_ba_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
+int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+/* DEVICE pointer + element count of the contiguous reduced buffer (doubles). */
+int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld);
+/* Bind an externally owned DEVICE buffer (e.g. a torch tensor) as the reduced buffer. */
+int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles);
+
+/* Parity hooks: per-observation terms and the reduced system at the given state (one linearisation,
+ * ba_processor.py:317-382).  S is (7V x 7V) row-major (both triangles filled), rhs (7V). */
+int sfm_ba_residual_jacobian(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx,
+                             const double* uv_norm, const double* cams, const double* pts, int quirks,
+                             double* r /*[M][2]*/, double* Jp /*[M][2][7]*/, double* Jx /*[M][2][3]*/);
+int sfm_ba_reduced_system(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx,
+                          const double* uv_norm, const double* cams, const double* pts,
+                          double lambda, int quirks, int schur_mode,
+                          double* S /*[7V][7V]*/, double* rhs /*[7V]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_HIP_H */

@@ -1,0 +1,67 @@
+// sfm_ba.h — device-side view and host-side object of a resident bundle-adjustment problem.
+#pragma once
+
+#include <utility>
+#include <vector>
+
+#include "sfm_common.h"
+
+namespace sfm {
+
+// Plain-data view passed by value to kernels (all pointers are device memory).
+struct BaDev {
+  int V = 0, N = 0;
+  long long M = 0;
+  int P = 0;    // 7 V
+  int ld = 0;   // leading dimension of S (P rounded up to 64)
+  // static structure: observations sorted by (point, camera)
+  int* pt_ptr = nullptr;    // [N+1]
+  int* cam_idx = nullptr;   // [M]
+  int* obs_pt = nullptr;    // [M] point of each observation (thread-per-observation kernels)
+  double* u = nullptr;      // [M] normalised keys
+  double* v = nullptr;      // [M]
+  // state
+  double* cams = nullptr;   // [V][7]
+  double* px = nullptr;     // [N] SoA points
+  double* py = nullptr;
+  double* pz = nullptr;
+  // per-iteration scratch
+  CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
+  double* Z = nullptr;      // [M][21]  Z_o = (Jp^T Jx) L_p^-T
+  double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
+  double* delta = nullptr;  // [ld] camera update
+  int* status = nullptr;    // [2] first failure code, camera index
+};
+
+struct KernelTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int used = 0;
+};
+
+constexpr unsigned kBaMagic = 0x5F3BA001u;
+
+}  // namespace sfm
+
+struct sfm_ba_problem {
+  unsigned magic = sfm::kBaMagic;
+  sfm::BaDev dev;
+  int cur = 0;               // which prep slot holds the cameras of the current state
+  bool prep_valid = false;
+  int max_track = 0;         // longest track (observations of one point)
+  int schur_mode = SFM_SCHUR_AUTO;
+  int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
+  double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
+  // Schur-product plan (sfm_ba_schur.hip)
+  void* schur_ws = nullptr;
+  int schur_chunks = 0;
+  int schur_pts_per_chunk = 0;
+  sfm::KernelTimer timers[SFM_K_COUNT];
+};
+
+namespace sfm {
+int ba_schur_plan(sfm_ba_problem* p);
+int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
+int ba_enqueue_prep(sfm_ba_problem* p);
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+}  // namespace sfm

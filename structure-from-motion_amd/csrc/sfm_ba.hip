@@ -1,0 +1,801 @@
+// sfm_ba.hip — bundle-adjustment kernels and the device-resident problem object (gfx950).
+//
+// One damped Gauss-Newton iteration of BaProcessor.__execute_bundle_adjustment
+// (ba_processor.py:297-406), restructured as a block-sparse Schur solve that never builds the
+// reference's dense J:
+//
+//   ba_cam_prep        per camera: R(q) (+ validity), canonical q^ from R, t = R^T(-C)     (ba:321-328, campose:464)
+//   ba_linearize<G>    G lanes per point, one observation per lane: r, Jp, Jx; wave-segment reduction of
+//                      V_p = sum Jx^T Jx + lambda I and g_p = sum Jx^T r; L_p = chol(V_p);
+//                      Z_o = (Jp^T Jx) L_p^-T -> HBM (21 doubles / obs);
+//                      U_c = sum Jp^T Jp and rhs_c = sum (Jp^T r - Z_o L_p^-1 g_p) accumulated in LDS
+//                      (ds_add_f64) per workgroup and flushed once with global f64 atomics            (ba:355-379)
+//   ba_schur_*         S -= sum_p Z_p Z_p^T  (= B D^-1 B^T, ba:382)                         [sfm_ba_schur.hip]
+//   ba_chol_panel      blocked left-looking Cholesky of S + lambda I with the rhs carried as an extra row
+//   ba_back_solve      L^T dp = y; cams += dp; q /= |q| (ba:383-392); cam_prep for the next iteration
+//   ba_backsub<G>      per point: recompute the linearisation from the 20 B/observation inputs and
+//                      dX = V_p^-1 (g_p - sum_o W_o^T dp_c); X += dX                          (ba:405-406)
+//
+// HBM layout: observations sorted by (point, camera) as a CSR over points; u[], v[] (normalised
+// keys), cam_idx[] SoA; points SoA X[], Y[], Z[]; cameras AoS [V][7]; reduced system
+// [S (ld x ld, lower triangle valid) | rhs (ld)] contiguous so one all-reduce covers both.
+#include <algorithm>
+#include <vector>
+
+#include "sfm_ba.h"
+
+namespace sfm {
+
+// ---------------------------------------------------------------------------------------------
+__global__ void ba_cam_prep_kernel(int V, const double* __restrict__ cams, CamPrep* __restrict__ prep,
+                                   int* __restrict__ status) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= V) return;
+  CamPrep out;
+  const int st = cam_prepare(cams + 7 * c, &out);
+  prep[c] = out;
+  report_status(status, st, c);
+}
+
+// Residual + Jacobians of one observation at the prepared camera (ba_processor.py:317-349).
+__device__ __forceinline__ void obs_terms(const CamPrep& c, double X, double Y, double Z, double u, double v,
+                                          int quirks, double* r, double* Jp, double* Jx) {
+  double p[3];
+  project_cam(c, X, Y, Z, 1.0, p);
+  jac_cam(c, X, Y, Z, p, quirks, Jp);
+  jac_pt_cam(c, p, Jx);
+  r[0] = u - p[0] / p[2];      // b - f (ba:376)
+  r[1] = v - p[1] / p[2];
+}
+
+__device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
+  const double* s = reinterpret_cast<const double*>(src);
+  double* d = reinterpret_cast<double*>(&dst);
+#pragma unroll
+  for (int k = 0; k < 19; ++k) d[k] = s[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// ba_linearize: G lanes per point (G = power of two <= 64 chosen from the mean track length).
+// LDS: [V][19] prepared cameras + [V][35] camera-side accumulators when they fit (CAMS_IN_LDS).
+// ---------------------------------------------------------------------------------------------
+template <int G, bool CAMS_IN_LDS>
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
+  extern __shared__ double lds[];
+  double* lds_prep = lds;                    // V * 19
+  double* lds_acc = lds + (size_t)d.V * 19;  // V * 35
+  const CamPrep* gprep = d.prep[cur];
+  if (CAMS_IN_LDS) {
+    const double* src = reinterpret_cast<const double*>(gprep);
+    for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_prep[i] = src[i];
+    for (int i = threadIdx.x; i < d.V * 35; i += blockDim.x) lds_acc[i] = 0.0;
+    __syncthreads();
+  }
+  constexpr int GPB = 256 / G;                 // point groups per block
+  const int lane_g = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)d.ld * d.ld;
+
+  for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
+    const int p = p0 + grp;
+    int beg = 0, end = 0;
+    double X = 0, Y = 0, Z = 0;
+    if (p < d.N) {
+      beg = d.pt_ptr[p]; end = d.pt_ptr[p + 1];
+      X = d.px[p]; Y = d.py[p]; Z = d.pz[p];
+    }
+    double v6[6] = {0, 0, 0, 0, 0, 0}, g3[3] = {0, 0, 0};
+    double r[2], Jp[14], Jx[6];
+    int cam = 0;
+    for (int o = beg + lane_g; o < end; o += G) {
+      cam = d.cam_idx[o];
+      CamPrep c;
+      load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
+      obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
+      v6[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
+      v6[1] += Jx[1] * Jx[0] + Jx[4] * Jx[3];
+      v6[2] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
+      v6[3] += Jx[2] * Jx[0] + Jx[5] * Jx[3];
+      v6[4] += Jx[2] * Jx[1] + Jx[5] * Jx[4];
+      v6[5] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
+      g3[0] += Jx[0] * r[0] + Jx[3] * r[1];
+      g3[1] += Jx[1] * r[0] + Jx[4] * r[1];
+      g3[2] += Jx[2] * r[0] + Jx[5] * r[1];
+    }
+#pragma unroll
+    for (int s = G / 2; s > 0; s >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v6[k] += __shfl_xor(v6[k], s, G);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g3[k] += __shfl_xor(g3[k], s, G);
+    }
+    v6[0] += lambda; v6[2] += lambda; v6[5] += lambda;     // ba:359
+    double li[6];
+    chol3_inv(v6, li);
+    const double y0 = li[0] * g3[0];
+    const double y1 = li[1] * g3[0] + li[2] * g3[1];
+    const double y2 = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
+    const bool single = (end - beg) <= G;
+    for (int o = beg + lane_g; o < end; o += G) {
+      if (!single) {
+        cam = d.cam_idx[o];
+        CamPrep c;
+        load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
+        obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
+      }
+      double* zo = d.Z + (size_t)o * 21;
+      double acc[35];
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        // W_i. = Jp[.][i]^T Jx (block B_{c,p}, ba:379);  Z_i. = W_i. L^-T
+        const double w0 = Jp[i] * Jx[0] + Jp[7 + i] * Jx[3];
+        const double w1 = Jp[i] * Jx[1] + Jp[7 + i] * Jx[4];
+        const double w2 = Jp[i] * Jx[2] + Jp[7 + i] * Jx[5];
+        const double z0 = w0 * li[0];
+        const double z1 = w0 * li[1] + w1 * li[2];
+        const double z2 = w0 * li[3] + w1 * li[4] + w2 * li[5];
+        zo[3 * i + 0] = z0; zo[3 * i + 1] = z1; zo[3 * i + 2] = z2;
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
+        acc[28 + i] = Jp[i] * r[0] + Jp[7 + i] * r[1] - (z0 * y0 + z1 * y1 + z2 * y2);
+      }
+      if (CAMS_IN_LDS) {
+        double* a = lds_acc + (size_t)cam * 35;
+#pragma unroll
+        for (int q = 0; q < 35; ++q) atomicAdd(a + q, acc[q]);
+      } else {
+        k = 0;
+        for (int i = 0; i < 7; ++i)
+          for (int j = 0; j <= i; ++j) { atomicAdd(&S[(size_t)(7 * cam + i) * d.ld + 7 * cam + j], acc[k]); ++k; }
+        for (int i = 0; i < 7; ++i) atomicAdd(&rhs[7 * cam + i], acc[28 + i]);
+      }
+    }
+  }
+  if (CAMS_IN_LDS) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) {
+      const double val = lds_acc[t];
+      if (val == 0.0) continue;
+      const int c = t / 35, e = t % 35;
+      if (e >= 28) {
+        atomicAdd(&rhs[7 * c + (e - 28)], val);
+      } else {
+        int i = 0, base = 0;                   // e = i(i+1)/2 + j
+        while (base + i + 1 <= e) { base += i + 1; ++i; }
+        const int j = e - base;
+        atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + j], val);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ba_backsub: dX_p = V_p^-1 (g_p - sum_o W_o^T dp_c), recomputing the linearisation at the
+// iteration's starting state (prep[cur] and the not-yet-updated points).
+// ---------------------------------------------------------------------------------------------
+template <int G, bool CAMS_IN_LDS>
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev d, int cur, double lambda, int quirks) {
+  extern __shared__ double lds[];
+  double* lds_prep = lds;                      // V * 19
+  double* lds_delta = lds + (size_t)d.V * 19;  // V * 7
+  const CamPrep* gprep = d.prep[cur];
+  if (CAMS_IN_LDS) {
+    const double* src = reinterpret_cast<const double*>(gprep);
+    for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_prep[i] = src[i];
+    for (int i = threadIdx.x; i < d.V * 7; i += blockDim.x) lds_delta[i] = d.delta[i];
+    __syncthreads();
+  }
+  constexpr int GPB = 256 / G;
+  const int lane_g = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
+    const int p = p0 + grp;
+    int beg = 0, end = 0;
+    double X = 0, Y = 0, Z = 0;
+    if (p < d.N) {
+      beg = d.pt_ptr[p]; end = d.pt_ptr[p + 1];
+      X = d.px[p]; Y = d.py[p]; Z = d.pz[p];
+    }
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // v6 | (g - W^T dp)
+    for (int o = beg + lane_g; o < end; o += G) {
+      const int cam = d.cam_idx[o];
+      CamPrep c;
+      load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
+      double r[2], Jp[14], Jx[6];
+      obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
+      const double* dp = CAMS_IN_LDS ? lds_delta + 7 * cam : d.delta + 7 * cam;
+      double e0 = r[0], e1 = r[1];               // r - Jp dp
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { e0 -= Jp[i] * dp[i]; e1 -= Jp[7 + i] * dp[i]; }
+      a[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
+      a[1] += Jx[1] * Jx[0] + Jx[4] * Jx[3];
+      a[2] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
+      a[3] += Jx[2] * Jx[0] + Jx[5] * Jx[3];
+      a[4] += Jx[2] * Jx[1] + Jx[5] * Jx[4];
+      a[5] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
+      a[6] += Jx[0] * e0 + Jx[3] * e1;
+      a[7] += Jx[1] * e0 + Jx[4] * e1;
+      a[8] += Jx[2] * e0 + Jx[5] * e1;
+    }
+#pragma unroll
+    for (int s = G / 2; s > 0; s >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] += __shfl_xor(a[k], s, G);
+    }
+    if (lane_g == 0 && p < d.N) {
+      a[0] += lambda; a[2] += lambda; a[5] += lambda;
+      double li[6];
+      chol3_inv(a, li);
+      const double y0 = li[0] * a[6];
+      const double y1 = li[1] * a[6] + li[2] * a[7];
+      const double y2 = li[3] * a[6] + li[4] * a[7] + li[5] * a[8];
+      d.px[p] = X + (li[0] * y0 + li[1] * y1 + li[3] * y2);     // L^-T y
+      d.py[p] = Y + (li[2] * y1 + li[4] * y2);
+      d.pz[p] = Z + (li[5] * y2);
+    }
+  }
+}
+
+// Parity hook: per-observation r / Jp / Jx (thread per observation).
+__global__ void ba_residual_jacobian_kernel(BaDev d, int cur, int quirks, const int* __restrict__ obs_pt,
+                                            double* __restrict__ r_out, double* __restrict__ Jp_out,
+                                            double* __restrict__ Jx_out) {
+  const long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (o >= d.M) return;
+  const int p = obs_pt[o];
+  CamPrep c;
+  load_cam(c, d.prep[cur] + d.cam_idx[o]);
+  double r[2], Jp[14], Jx[6];
+  obs_terms(c, d.px[p], d.py[p], d.pz[p], d.u[o], d.v[o], quirks, r, Jp, Jx);
+  r_out[2 * o] = r[0]; r_out[2 * o + 1] = r[1];
+  for (int k = 0; k < 14; ++k) Jp_out[14 * o + k] = Jp[k];
+  for (int k = 0; k < 6; ++k) Jx_out[6 * o + k] = Jx[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduced solve.  S (+ lambda I) = L L^T by a blocked left-looking Cholesky, one launch per 32-wide
+// panel; workgroup b owns the 32-row block b of the panel (block 0 = the diagonal block) and the last
+// workgroup owns the rhs row, which rides along as an extra matrix row so the forward solve L y = rhs
+// needs no pass of its own.  Every workgroup recomputes and factors the 32x32 diagonal block
+// (cheap) instead of waiting for another workgroup.  L overwrites the lower triangle of S.
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 32;
+
+__global__ __launch_bounds__(256) void ba_chol_panel_kernel(double* __restrict__ S, double* __restrict__ rhs, int ld,
+                                                            int P, int c0, double lambda) {
+  __shared__ double Ld[NB][NB + 1];   // diagonal block, then its Cholesky factor
+  __shared__ double T[NB][NB + 1];    // this workgroup's row block
+  __shared__ double Lc[NB][NB + 1];   // K-chunk of the panel's block row  L[c0.., kc..]
+  __shared__ double Lr[NB][NB + 1];   // K-chunk of this workgroup's rows   L[r0.., kc..]
+  const int nb = min(NB, P - c0);
+  const int nrb = (P - c0 + NB - 1) / NB;
+  const int rb = blockIdx.x;            // 0..nrb-1 row blocks, nrb = rhs row
+  const bool is_rhs = rb == nrb;
+  const int r0 = c0 + rb * NB;
+  const int nr = is_rhs ? 1 : min(NB, P - r0);
+  const int tid = threadIdx.x;
+  const int ti = tid / NB, tj = tid % NB;     // 8 x 32 thread grid; each thread owns rows ti + 8e
+
+  double accD[4] = {0, 0, 0, 0}, accT[4] = {0, 0, 0, 0};
+  for (int kc = 0; kc < c0; kc += NB) {
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      Lc[i][tj] = (i < nb) ? S[(size_t)(c0 + i) * ld + kc + tj] : 0.0;
+      double v = 0.0;
+      if (i < nr) v = is_rhs ? rhs[kc + tj] : S[(size_t)(r0 + i) * ld + kc + tj];
+      Lr[i][tj] = v;
+    }
+    __syncthreads();
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      double sd = 0, st = 0;
+#pragma unroll 8
+      for (int k = 0; k < NB; ++k) {
+        const double cj = Lc[tj][k];
+        sd += Lc[i][k] * cj;
+        st += Lr[i][k] * cj;
+      }
+      accD[e] += sd;
+      accT[e] += st;
+    }
+    __syncthreads();
+  }
+  for (int e = 0; e < 4; ++e) {
+    const int i = ti + 8 * e;
+    double dv = 0.0, tv = 0.0;
+    if (i < nb && tj < nb && tj <= i) dv = S[(size_t)(c0 + i) * ld + c0 + tj] + (i == tj ? lambda : 0.0) - accD[e];
+    if (i < nr && tj < nb) tv = (is_rhs ? rhs[c0 + tj] : S[(size_t)(r0 + i) * ld + c0 + tj]) - accT[e];
+    Ld[i][tj] = dv;
+    T[i][tj] = tv;
+  }
+  __syncthreads();
+  // factor the diagonal block in LDS (right-looking, nb steps)
+  for (int j = 0; j < nb; ++j) {
+    const double djj = sqrt(Ld[j][j]);
+    __syncthreads();
+    if (tid < nb && tid >= j) Ld[tid][j] = (tid == j) ? djj : Ld[tid][j] / djj;
+    __syncthreads();
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      if (i > j && tj > j && tj <= i && i < nb) Ld[i][tj] -= Ld[i][j] * Ld[tj][j];
+    }
+    __syncthreads();
+  }
+  if (rb == 0) {
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      if (i < nb && tj <= i) S[(size_t)(c0 + i) * ld + c0 + tj] = Ld[i][tj];
+    }
+  } else {
+    // X Ld^T = T : one thread per row, forward substitution over the nb columns
+    if (tid < nr) {
+      for (int j = 0; j < nb; ++j) {
+        double s = T[tid][j];
+        for (int k = 0; k < j; ++k) s -= T[tid][k] * Ld[j][k];
+        T[tid][j] = s / Ld[j][j];
+      }
+    }
+    __syncthreads();
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      if (i < nr && tj < nb) {
+        if (is_rhs) rhs[c0 + tj] = T[i][tj];
+        else S[(size_t)(r0 + i) * ld + c0 + tj] = T[i][tj];
+      }
+    }
+  }
+}
+
+// L^T dp = y (y sits in rhs after the panels), then the camera update of ba:383-392 and the
+// preparation of the next iteration's cameras.  Single workgroup.
+__global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
+  __shared__ double Ld[NB][NB + 1];
+  __shared__ double xb[NB];
+  const int P = d.P, ld = d.ld;
+  const double* S = d.red;
+  double* y = d.red + (size_t)ld * ld;
+  const int tid = threadIdx.x;
+  const int nblk = (P + NB - 1) / NB;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int c0 = b * NB;
+    const int nb = min(NB, P - c0);
+    for (int t = tid; t < NB * NB; t += blockDim.x) {
+      const int i = t / NB, j = t % NB;
+      Ld[i][j] = (i < nb && j <= i) ? S[(size_t)(c0 + i) * ld + c0 + j] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // one wave: lane i holds y_i of the block; columns are eliminated from the last to the first
+      double yi = (tid < nb) ? y[c0 + tid] : 0.0;
+      for (int j = nb - 1; j >= 0; --j) {
+        const double xj = __shfl(yi, j, 64) / Ld[j][j];
+        if (tid == j) yi = xj;
+        else if (tid < j) yi -= Ld[j][tid] * xj;
+      }
+      if (tid < nb) { xb[tid] = yi; d.delta[c0 + tid] = yi; }
+    }
+    __syncthreads();
+    for (int i = tid; i < c0; i += blockDim.x) {
+      double s = 0;
+      for (int k = 0; k < nb; ++k) s += S[(size_t)(c0 + k) * ld + i] * xb[k];
+      y[i] -= s;
+    }
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = tid; c < d.V; c += blockDim.x) {
+    double cam[7];
+    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383
+    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
+    for (int k = 3; k < 7; ++k) cam[k] /= nq;
+    for (int k = 0; k < 7; ++k) d.cams[7 * c + k] = cam[k];
+    CamPrep out;
+    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
+    d.prep[cur ^ 1][c] = out;
+    report_status(d.status, st, c);
+  }
+}
+
+// S (lower) -> dense symmetric host-visible copy for the parity hook.
+__global__ void ba_symmetrize_kernel(const double* __restrict__ S, int ld, int P, double lambda, double* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * P) return;
+  const int i = idx / P, j = idx % P;
+  const int a = max(i, j), b = min(i, j);
+  out[idx] = S[(size_t)a * ld + b] + (i == j ? lambda : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int pick_group(const sfm_ba_problem* p) {
+  // lanes per point: smallest power of two >= mean track length (clamped to [4, 64]); longer tracks loop
+  double mean = p->dev.N > 0 ? (double)p->dev.M / p->dev.N : 1.0;
+  int g = 4;
+  while (g < 64 && g < mean) g <<= 1;
+  return g;
+}
+
+template <bool LDS>
+static void launch_linearize(const sfm_ba_problem* p, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
+  const BaDev& d = p->dev;
+  switch (g) {
+    case 4: ba_linearize_kernel<4, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 8: ba_linearize_kernel<8, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 16: ba_linearize_kernel<16, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 32: ba_linearize_kernel<32, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    default: ba_linearize_kernel<64, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+  }
+}
+
+template <bool LDS>
+static void launch_backsub(const sfm_ba_problem* p, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
+  const BaDev& d = p->dev;
+  switch (g) {
+    case 4: ba_backsub_kernel<4, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 8: ba_backsub_kernel<8, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 16: ba_backsub_kernel<16, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 32: ba_backsub_kernel<32, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    default: ba_backsub_kernel<64, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+  }
+}
+
+static void tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
+  if (!(p->timing & (1 << kid))) return;
+  KernelTimer& t = p->timers[kid];
+  if (begin) {
+    if (t.used == (int)t.ev.size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      t.ev.push_back({a, b});
+    }
+    (void)hipEventRecord(t.ev[t.used].first, s);
+  } else {
+    (void)hipEventRecord(t.ev[t.used].second, s);
+    t.used++;
+  }
+}
+
+int ba_enqueue_prep(sfm_ba_problem* p) {
+  hipStream_t s = ctx().stream;
+  const BaDev& d = p->dev;
+  tick(p, SFM_K_PREP, true, s);
+  ba_cam_prep_kernel<<<(d.V + 63) / 64, 64, 0, s>>>(d.V, d.cams, d.prep[p->cur], d.status);
+  tick(p, SFM_K_PREP, false, s);
+  SFM_HIP(hipGetLastError());
+  p->prep_valid = true;
+  return SFM_OK;
+}
+
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+  hipStream_t s = ctx().stream;
+  const BaDev& d = p->dev;
+  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
+  SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
+  const int g = pick_group(p);
+  const int gpb = 256 / g;
+  int grid = std::min((d.N + gpb - 1) / gpb, 2 * ctx().num_cus);
+  if (grid < 1) grid = 1;
+  const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);
+  tick(p, SFM_K_LINEARIZE, true, s);
+  if (lds <= 64 * 1024) launch_linearize<true>(p, g, grid, lds, s, lambda, quirks);
+  else launch_linearize<false>(p, g, grid, 0, s, lambda, quirks);
+  tick(p, SFM_K_LINEARIZE, false, s);
+  SFM_HIP(hipGetLastError());
+  tick(p, SFM_K_SCHUR, true, s);
+  SFM_TRY(ba_enqueue_schur(p, s));
+  tick(p, SFM_K_SCHUR, false, s);
+  return SFM_OK;
+}
+
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
+  hipStream_t s = ctx().stream;
+  const BaDev& d = p->dev;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)d.ld * d.ld;
+  tick(p, SFM_K_SOLVE, true, s);
+  for (int c0 = 0; c0 < d.P; c0 += NB) {
+    const int nrb = (d.P - c0 + NB - 1) / NB;
+    ba_chol_panel_kernel<<<nrb + 1, 256, 0, s>>>(S, rhs, d.ld, d.P, c0, lambda);
+  }
+  ba_back_solve_kernel<<<1, 256, 0, s>>>(d, p->cur);
+  tick(p, SFM_K_SOLVE, false, s);
+  SFM_HIP(hipGetLastError());
+  const int g = pick_group(p);
+  const int gpb = 256 / g;
+  int grid = std::min((d.N + gpb - 1) / gpb, 4 * ctx().num_cus);
+  if (grid < 1) grid = 1;
+  const size_t lds = sizeof(double) * (size_t)d.V * (19 + 7);
+  tick(p, SFM_K_BACKSUB, true, s);
+  if (lds <= 64 * 1024) launch_backsub<true>(p, g, grid, lds, s, lambda, quirks);
+  else launch_backsub<false>(p, g, grid, 0, s, lambda, quirks);
+  tick(p, SFM_K_BACKSUB, false, s);
+  SFM_HIP(hipGetLastError());
+  p->cur ^= 1;      // ba_back_solve_kernel prepared the updated cameras into the other slot
+  return SFM_OK;
+}
+
+static int check_problem(const sfm_ba_problem* p) {
+  if (p == nullptr || p->magic != kBaMagic) {
+    set_error("invalid bundle-adjustment problem handle");
+    return SFM_E_HANDLE;
+  }
+  return SFM_OK;
+}
+
+static const char* status_name(int st) {
+  switch (st) {
+    case SFM_E_BAD_ROTATION: return "invalid rotation matrix";
+    case SFM_E_QW_ZERO: return "quaternion qw ~ 0";
+    case SFM_E_SQRT_DOMAIN: return "1 + trace(R) < 0";
+    default: return "unknown";
+  }
+}
+
+}  // namespace sfm
+
+using namespace sfm;
+
+extern "C" {
+
+int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                  sfm_ba_problem** out) {
+  SFM_TRY(ensure_init());
+  if (out == nullptr) { set_error("sfm_ba_create: out is null"); return SFM_E_SHAPE; }
+  *out = nullptr;
+  if (V < 1 || N < 0 || M < 0 || M > 0x7fffffffLL) {
+    set_error("sfm_ba_create: bad sizes V=%d N=%d M=%lld", V, N, (long long)M);
+    return SFM_E_SHAPE;
+  }
+  if (N > 0 && (pt_ptr[0] != 0 || pt_ptr[N] != M)) { set_error("sfm_ba_create: pt_ptr must span [0, M]"); return SFM_E_SHAPE; }
+  int max_k = 0;
+  std::vector<int> obs_pt((size_t)M);
+  for (int p = 0; p < N; ++p) {
+    const int k = pt_ptr[p + 1] - pt_ptr[p];
+    if (k < 0) { set_error("sfm_ba_create: pt_ptr not monotone at point %d", p); return SFM_E_SHAPE; }
+    max_k = std::max(max_k, k);
+    for (int o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
+      if (cam_idx[o] < 0 || cam_idx[o] >= V) { set_error("sfm_ba_create: cam_idx[%d]=%d out of range", o, cam_idx[o]); return SFM_E_SHAPE; }
+      if (o > pt_ptr[p] && cam_idx[o] <= cam_idx[o - 1]) {
+        set_error("sfm_ba_create: observations of point %d are not sorted by strictly increasing camera", p);
+        return SFM_E_SHAPE;
+      }
+      obs_pt[o] = p;
+    }
+  }
+  sfm_ba_problem* p = new sfm_ba_problem();
+  BaDev& d = p->dev;
+  d.V = V; d.N = N; d.M = M; d.P = 7 * V;
+  d.ld = ((d.P + 63) / 64) * 64;
+  p->max_track = max_k;
+  hipStream_t s = ctx().stream;
+  auto fail = [&](int st) { sfm_ba_destroy(p); return st; };
+#define BA_ALLOC(ptr, count) do { hipError_t e_ = hipMalloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
+    if (e_ != hipSuccess) return fail(hip_fail(e_, "hipMalloc " #ptr, __LINE__)); } while (0)
+  BA_ALLOC(d.pt_ptr, (size_t)N + 1);
+  BA_ALLOC(d.cam_idx, (size_t)M);
+  BA_ALLOC(d.obs_pt, (size_t)M);
+  BA_ALLOC(d.u, (size_t)M);
+  BA_ALLOC(d.v, (size_t)M);
+  BA_ALLOC(d.cams, (size_t)V * 7);
+  BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
+  BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
+  BA_ALLOC(d.Z, (size_t)M * 21);
+  BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
+  BA_ALLOC(d.delta, (size_t)d.ld);
+  BA_ALLOC(d.status, 2);
+#undef BA_ALLOC
+  d.red = p->own_red;
+  const int zero_ptr = 0;
+  if (N > 0) { if (hipMemcpyAsync(d.pt_ptr, pt_ptr, sizeof(int) * ((size_t)N + 1), hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP); }
+  else { if (hipMemcpyAsync(d.pt_ptr, &zero_ptr, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP); }
+  if (M > 0) {
+    if (hipMemcpyAsync(d.cam_idx, cam_idx, sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+    if (hipMemcpyAsync(d.obs_pt, obs_pt.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+    if (hipMemcpyAsync(d.u, uv_norm, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+    if (hipMemcpyAsync(d.v, uv_norm + M, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+  }
+  if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), s) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, s) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(SFM_E_HIP);
+  SFM_TRY(ba_schur_plan(p));
+  *out = p;
+  return SFM_OK;
+}
+
+int sfm_ba_destroy(sfm_ba_problem* p) {
+  if (p == nullptr) return SFM_OK;
+  if (p->magic != kBaMagic) { set_error("sfm_ba_destroy: invalid handle"); return SFM_E_HANDLE; }
+  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  BaDev& d = p->dev;
+  void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
+                  d.Z, p->own_red, d.delta, d.status, p->schur_ws};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (auto& t : p->timers)
+    for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  p->magic = 0;
+  delete p;
+  return SFM_OK;
+}
+
+int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
+  SFM_TRY(check_problem(p));
+  switch (option) {
+    case SFM_OPT_SCHUR:
+      if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
+      p->schur_mode = value;
+      return SFM_OK;
+    case SFM_OPT_TIMING:
+      p->timing = value;   // bit k set = time kernel class k
+      return SFM_OK;
+    default:
+      set_error("unknown option %d", option);
+      return SFM_E_SHAPE;
+  }
+}
+
+int sfm_ba_set_state(sfm_ba_problem* p, const double* cams, const double* pts) {
+  SFM_TRY(check_problem(p));
+  hipStream_t s = ctx().stream;
+  BaDev& d = p->dev;
+  SFM_HIP(hipMemcpyAsync(d.cams, cams, sizeof(double) * 7 * d.V, hipMemcpyHostToDevice, s));
+  if (d.N > 0) {
+    SFM_HIP(hipMemcpyAsync(d.px, pts, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
+    SFM_HIP(hipMemcpyAsync(d.py, pts + d.N, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
+    SFM_HIP(hipMemcpyAsync(d.pz, pts + 2 * (size_t)d.N, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
+  }
+  SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), s));
+  SFM_HIP(hipStreamSynchronize(s));
+  p->prep_valid = false;
+  return SFM_OK;
+}
+
+int sfm_ba_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+  SFM_TRY(check_problem(p));
+  return ba_enqueue_linearize_reduce(p, lambda, quirks);
+}
+
+int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
+  SFM_TRY(check_problem(p));
+  return ba_enqueue_solve_update(p, lambda, quirks);
+}
+
+int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks) {
+  SFM_TRY(check_problem(p));
+  if (iters < 0) { set_error("sfm_ba_iterate: iters < 0"); return SFM_E_SHAPE; }
+  for (int it = 0; it < iters; ++it) {
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
+  }
+  return SFM_OK;
+}
+
+int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
+  SFM_TRY(check_problem(p));
+  hipStream_t s = ctx().stream;
+  BaDev& d = p->dev;
+  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));     // validates the cameras even with zero iterations (ba:412)
+  int st[2] = {0, 0};
+  SFM_HIP(hipMemcpyAsync(cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToHost, s));
+  if (d.N > 0) {
+    SFM_HIP(hipMemcpyAsync(pts, d.px, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipMemcpyAsync(pts + d.N, d.py, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipMemcpyAsync(pts + 2 * (size_t)d.N, d.pz, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+  }
+  SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  if (st[0] != SFM_OK) {
+    set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]);
+    return st[0];
+  }
+  return SFM_OK;
+}
+
+int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {
+  SFM_TRY(check_problem(p));
+  if (device_ptr) *device_ptr = p->dev.red;
+  if (n_doubles) *n_doubles = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  if (ld) *ld = p->dev.ld;
+  return SFM_OK;
+}
+
+int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
+  SFM_TRY(check_problem(p));
+  const int64_t need = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
+  if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }
+  p->dev.red = static_cast<double*>(device_ptr);
+  return SFM_OK;
+}
+
+int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches) {
+  SFM_TRY(check_problem(p));
+  if (kernel_id < 0 || kernel_id >= SFM_K_COUNT) { set_error("bad kernel id %d", kernel_id); return SFM_E_SHAPE; }
+  SFM_HIP(hipStreamSynchronize(ctx().stream));
+  KernelTimer& t = p->timers[kernel_id];
+  double tot = 0;
+  for (int i = 0; i < t.used; ++i) {
+    float ms = 0;
+    SFM_HIP(hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = t.used;
+  return SFM_OK;
+}
+
+int sfm_ba_reset_timing(sfm_ba_problem* p) {
+  SFM_TRY(check_problem(p));
+  SFM_HIP(hipStreamSynchronize(ctx().stream));
+  for (auto& t : p->timers) t.used = 0;
+  return SFM_OK;
+}
+
+int sfm_ba_solve(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm, double* cams,
+                 double* pts, double lambda, int iters, int quirks) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  int st = sfm_ba_set_state(p, cams, pts);
+  if (st == SFM_OK) st = sfm_ba_iterate(p, lambda, iters, quirks);
+  if (st == SFM_OK) st = sfm_ba_get_state(p, cams, pts);
+  sfm_ba_destroy(p);
+  return st;
+}
+
+int sfm_ba_residual_jacobian(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                             const double* cams, const double* pts, int quirks, double* r, double* Jp, double* Jx) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  auto run = [&]() -> int {
+    SFM_TRY(sfm_ba_set_state(p, cams, pts));
+    SFM_TRY(ba_enqueue_prep(p));
+    if (M == 0) return SFM_OK;
+    hipStream_t s = ctx().stream;
+    DevBuf<double> dr, djp, djx;
+    SFM_TRY(dr.alloc(2 * (size_t)M)); SFM_TRY(djp.alloc(14 * (size_t)M)); SFM_TRY(djx.alloc(6 * (size_t)M));
+    ba_residual_jacobian_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(p->dev, p->cur, quirks, p->dev.obs_pt, dr.p, djp.p, djx.p);
+    SFM_HIP(hipGetLastError());
+    SFM_TRY(dr.download(r, 2 * (size_t)M, s)); SFM_TRY(djp.download(Jp, 14 * (size_t)M, s)); SFM_TRY(djx.download(Jx, 6 * (size_t)M, s));
+    int st[2] = {0, 0};
+    SFM_HIP(hipMemcpyAsync(st, p->dev.status, sizeof(st), hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipStreamSynchronize(s));
+    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
+    return SFM_OK;
+  };
+  const int st = run();
+  sfm_ba_destroy(p);
+  return st;
+}
+
+int sfm_ba_reduced_system(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                          const double* cams, const double* pts, double lambda, int quirks, int schur_mode, double* S,
+                          double* rhs) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  auto run = [&]() -> int {
+    SFM_TRY(sfm_ba_set_option(p, SFM_OPT_SCHUR, schur_mode));
+    SFM_TRY(sfm_ba_set_state(p, cams, pts));
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    hipStream_t s = ctx().stream;
+    const BaDev& d = p->dev;
+    DevBuf<double> dS;
+    SFM_TRY(dS.alloc((size_t)d.P * d.P));
+    ba_symmetrize_kernel<<<(d.P * d.P + 255) / 256, 256, 0, s>>>(d.red, d.ld, d.P, lambda, dS.p);
+    SFM_HIP(hipGetLastError());
+    SFM_TRY(dS.download(S, (size_t)d.P * d.P, s));
+    SFM_HIP(hipMemcpyAsync(rhs, d.red + (size_t)d.ld * d.ld, sizeof(double) * d.P, hipMemcpyDeviceToHost, s));
+    int st[2] = {0, 0};
+    SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipStreamSynchronize(s));
+    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
+    return SFM_OK;
+  };
+  const int st = run();
+  sfm_ba_destroy(p);
+  return st;
+}
+
+}  // extern "C"

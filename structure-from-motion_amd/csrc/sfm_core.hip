@@ -1,0 +1,498 @@
+// sfm_core.hip — library context + unit-level hooks + the per-point nonlinear triangulation kernel
+// and the per-view nonlinear PnP kernel (gfx950).
+//
+//   tri_nonlinear_kernel  <-> TriangulationProcessor.nonlinear_triangulate (triangulation_processor.py:160-234)
+//   pnp_nonlinear_kernel  <-> CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459)
+#include <cstring>
+#include <vector>
+
+#include "sfm_common.h"
+
+namespace sfm {
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, int line) {
+  set_error("HIP error '%s' in %s (line %d)", hipGetErrorString(e), what, line);
+  return SFM_E_HIP;
+}
+
+int ensure_init() {
+  if (ctx().inited) return SFM_OK;
+  return sfm_init(0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-level kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void quat_to_rot_kernel(int n, const double* q, double* R, int* status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r[9];
+  quat_to_rot(q + 4 * i, r);
+  for (int k = 0; k < 9; ++k) R[9 * i + k] = r[k];
+  status[i] = verify_rotation(r) ? SFM_OK : SFM_E_BAD_ROTATION;
+}
+
+__global__ void rot_to_quat_kernel(int n, const double* R, double* q, int* status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r[9], qq[4] = {0, 0, 0, 0};
+  for (int k = 0; k < 9; ++k) r[k] = R[9 * i + k];
+  status[i] = rot_to_quat(r, qq);
+  for (int k = 0; k < 4; ++k) q[4 * i + k] = qq[k];
+}
+
+__global__ void jac_cam_kernel(int n, const double* R, const double* C, const double* X, int quirks,
+                               double* Jp, int* status) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  CamPrep c;
+  double r[9], cc[3];
+  for (int k = 0; k < 9; ++k) r[k] = R[9 * i + k];
+  for (int k = 0; k < 3; ++k) cc[k] = C[3 * i + k];
+  int st = cam_prepare_rc(r, cc, &c);
+  status[i] = st;
+  double jp[14];
+  for (int k = 0; k < 14; ++k) jp[k] = 0;
+  if (st == SFM_OK) {
+    double p[3];
+    const double* x = X + 4 * i;
+    project_cam(c, x[0], x[1], x[2], x[3], p);
+    jac_cam(c, x[0], x[1], x[2], p, quirks, jp);
+  }
+  for (int k = 0; k < 14; ++k) Jp[14 * i + k] = jp[k];
+}
+
+__global__ void jac_pt_kernel(int n, int n_views, const double* projs, const double* X, double* Jx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* x = X + 4 * i;
+  for (int v = 0; v < n_views; ++v) {
+    const double* P = projs + (size_t)(i * n_views + v) * 12;
+    double s[3], j[6];
+    for (int r = 0; r < 3; ++r) s[r] = P[4 * r] * x[0] + P[4 * r + 1] * x[1] + P[4 * r + 2] * x[2] + P[4 * r + 3] * x[3];
+    jac_pt(P, s, j);
+    for (int k = 0; k < 6; ++k) Jx[(size_t)(i * n_views + v) * 6 + k] = j[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nonlinear triangulation: one thread per point, every iteration in registers.
+//   e = f - b, J (2V x 3) with the pixel projections, delta = inv(J^T J + lambda I3) J^T e, X -= delta
+// (triangulation_processor.py:209-228).  Projections are wave-uniform -> staged in LDS; the
+// uv / X arrays are SoA so consecutive lanes read consecutive doubles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTriLdsViews = 512;
+
+__global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, const double* __restrict__ projs,
+                                                            const double* __restrict__ uv,
+                                                            const double* __restrict__ Xin, double lambda, int iters,
+                                                            double* __restrict__ Xout) {
+  extern __shared__ double lds_proj[];
+  const bool in_lds = n_views <= kTriLdsViews;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < n_views * 12; i += blockDim.x) lds_proj[i] = projs[i];
+    __syncthreads();
+  }
+  const double* P_all = in_lds ? lds_proj : projs;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  double x0 = Xin[p], x1 = Xin[(size_t)m + p], x2 = Xin[2 * (size_t)m + p];
+  const double x3 = Xin[3 * (size_t)m + p];
+  for (int it = 0; it < iters; ++it) {
+    double a00 = 0, a10 = 0, a11 = 0, a20 = 0, a21 = 0, a22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int v = 0; v < n_views; ++v) {
+      const double* P = P_all + 12 * v;
+      double s[3], j[6];
+      for (int r = 0; r < 3; ++r) s[r] = P[4 * r] * x0 + P[4 * r + 1] * x1 + P[4 * r + 2] * x2 + P[4 * r + 3] * x3;
+      jac_pt(P, s, j);
+      const double eu = s[0] / s[2] - uv[((size_t)v * 2 + 0) * m + p];
+      const double ev = s[1] / s[2] - uv[((size_t)v * 2 + 1) * m + p];
+      a00 += j[0] * j[0] + j[3] * j[3];
+      a10 += j[1] * j[0] + j[4] * j[3];
+      a11 += j[1] * j[1] + j[4] * j[4];
+      a20 += j[2] * j[0] + j[5] * j[3];
+      a21 += j[2] * j[1] + j[5] * j[4];
+      a22 += j[2] * j[2] + j[5] * j[5];
+      b0 += j[0] * eu + j[3] * ev;
+      b1 += j[1] * eu + j[4] * ev;
+      b2 += j[2] * eu + j[5] * ev;
+    }
+    a00 += lambda; a11 += lambda; a22 += lambda;
+    // symmetric 3x3 inverse by adjugate (np.linalg.inv in the reference, tri:227)
+    const double c00 = a11 * a22 - a21 * a21;
+    const double c10 = a20 * a21 - a10 * a22;
+    const double c20 = a10 * a21 - a20 * a11;
+    const double det = a00 * c00 + a10 * c10 + a20 * c20;
+    const double id = 1.0 / det;
+    const double c11 = a00 * a22 - a20 * a20;
+    const double c21 = a10 * a20 - a00 * a21;
+    const double c22 = a00 * a11 - a10 * a10;
+    x0 -= (c00 * b0 + c10 * b1 + c20 * b2) * id;
+    x1 -= (c10 * b0 + c11 * b1 + c21 * b2) * id;
+    x2 -= (c20 * b0 + c21 * b1 + c22 * b2) * id;
+  }
+  Xout[p] = x0;
+  Xout[(size_t)m + p] = x1;
+  Xout[2 * (size_t)m + p] = x2;
+  Xout[3 * (size_t)m + p] = x3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nonlinear PnP: one workgroup per view.  Per iteration every thread linearises its points and
+// keeps the lower triangle of J^T J (28) and J^T e (7) in registers; a wave reduction + 4-wave LDS
+// sum gives the 7x7 normal equations; one lane solves them, updates the parameter block,
+// re-normalises the quaternion and rebuilds R(q) for the next iteration.
+// Quirk Q1 (default): the reference stores each point's 2 rows at [pt : pt+2], so only the u-row of
+// every point and the v-row of the LAST point survive (campose_processor.py:404-405).
+// ---------------------------------------------------------------------------------------------
+__device__ void solve7(double* A /*7x7 row-major, destroyed*/, double* b /*in: rhs, out: solution*/) {
+  // Gaussian elimination with partial pivoting (the reference uses np.linalg.inv = LU, campose:409)
+  for (int k = 0; k < 7; ++k) {
+    int piv = k;
+    double best = fabs(A[7 * k + k]);
+    for (int r = k + 1; r < 7; ++r)
+      if (fabs(A[7 * r + k]) > best) { best = fabs(A[7 * r + k]); piv = r; }
+    if (piv != k) {
+      for (int c = 0; c < 7; ++c) { double t = A[7 * k + c]; A[7 * k + c] = A[7 * piv + c]; A[7 * piv + c] = t; }
+      double t = b[k]; b[k] = b[piv]; b[piv] = t;
+    }
+    const double inv = 1.0 / A[7 * k + k];
+    for (int r = k + 1; r < 7; ++r) {
+      const double f = A[7 * r + k] * inv;
+      for (int c = k + 1; c < 7; ++c) A[7 * r + c] -= f * A[7 * k + c];
+      b[r] -= f * b[k];
+    }
+  }
+  for (int k = 6; k >= 0; --k) {
+    double s = b[k];
+    for (int c = k + 1; c < 7; ++c) s -= A[7 * k + c] * b[c];
+    b[k] = s / A[7 * k + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
+                                                            const double* __restrict__ uv_pix,
+                                                            const double* __restrict__ X,
+                                                            const double* __restrict__ Kmat,
+                                                            const double* __restrict__ R0,
+                                                            const double* __restrict__ C0, double lambda, int iters,
+                                                            int quirks, double* __restrict__ R_out,
+                                                            double* __restrict__ C_out, int* __restrict__ status) {
+  __shared__ CamPrep cam;
+  __shared__ double params[7];
+  __shared__ double kinv[9];
+  __shared__ double red[4][35];
+  __shared__ int st_sh;
+  const int view = blockIdx.x;
+  const int base = offsets[view];
+  const int n = offsets[view + 1] - base;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  if (tid == 0) {
+    const double* K = Kmat + 9 * view;
+    const double det = det3(K);
+    const double id = 1.0 / det;
+    kinv[0] = (K[4] * K[8] - K[5] * K[7]) * id; kinv[1] = (K[2] * K[7] - K[1] * K[8]) * id; kinv[2] = (K[1] * K[5] - K[2] * K[4]) * id;
+    kinv[3] = (K[5] * K[6] - K[3] * K[8]) * id; kinv[4] = (K[0] * K[8] - K[2] * K[6]) * id; kinv[5] = (K[2] * K[3] - K[0] * K[5]) * id;
+    kinv[6] = (K[3] * K[7] - K[4] * K[6]) * id; kinv[7] = (K[1] * K[6] - K[0] * K[7]) * id; kinv[8] = (K[0] * K[4] - K[1] * K[3]) * id;
+    // campose:361-371: q0 = q(R0) / |q(R0)|; iteration 0 linearises at (R0, C0) themselves
+    int st = cam_prepare_rc(R0 + 9 * view, C0 + 3 * view, &cam);
+    double nq = sqrt(cam.q[0] * cam.q[0] + cam.q[1] * cam.q[1] + cam.q[2] * cam.q[2] + cam.q[3] * cam.q[3]);
+    for (int k = 0; k < 3; ++k) params[k] = C0[3 * view + k];
+    for (int k = 0; k < 4; ++k) params[3 + k] = cam.q[k] / nq;
+    st_sh = st;
+  }
+  __syncthreads();
+
+  for (int it = 0; it < iters && st_sh == SFM_OK; ++it) {
+    double acc[35];
+#pragma unroll
+    for (int k = 0; k < 35; ++k) acc[k] = 0;
+    for (int p = tid; p < n; p += blockDim.x) {
+      const size_t col = (size_t)base + p;
+      const double x = X[col], y = X[(size_t)total + col], z = X[2 * (size_t)total + col], w = X[3 * (size_t)total + col];
+      const double u = uv_pix[col], v = uv_pix[(size_t)total + col], h = uv_pix[2 * (size_t)total + col];
+      double pc[3], jp[14];
+      project_cam(cam, x, y, z, w, pc);
+      jac_cam(cam, x, y, z, pc, quirks, jp);
+      const double m2 = kinv[6] * u + kinv[7] * v + kinv[8] * h;
+      const double eu = (kinv[0] * u + kinv[1] * v + kinv[2] * h) / m2 - pc[0] / pc[2];
+      const double ev = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2 - pc[1] / pc[2];
+      const bool use_v = !(quirks & SFM_Q1_PNP_ROW_OVERLAP) || (p == n - 1);
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { acc[k] += jp[i] * jp[j]; ++k; }
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) acc[28 + i] += jp[i] * eu;
+      if (use_v) {
+        k = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) { acc[k] += jp[7 + i] * jp[7 + j]; ++k; }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) acc[28 + i] += jp[7 + i] * ev;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 35; ++k) {
+      const double s = wave_sum(acc[k]);
+      if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double A[49], b[7];
+      int k = 0;
+      for (int i = 0; i < 7; ++i)
+        for (int j = 0; j <= i; ++j) {
+          const double s = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+          A[7 * i + j] = s;
+          A[7 * j + i] = s;
+          ++k;
+        }
+      for (int i = 0; i < 7; ++i) {
+        A[7 * i + i] += lambda;
+        b[i] = red[0][28 + i] + red[1][28 + i] + red[2][28 + i] + red[3][28 + i];
+      }
+      solve7(A, b);
+      for (int i = 0; i < 7; ++i) params[i] += b[i];
+      const double nq = sqrt(params[3] * params[3] + params[4] * params[4] + params[5] * params[5] + params[6] * params[6]);
+      for (int i = 3; i < 7; ++i) params[i] /= nq;
+      // campose:422: R = R(q) validated; the next Jacobian re-derives q from R (campose:464)
+      int st = cam_prepare(params, &cam);
+      if (st != SFM_OK) st_sh = st;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (iters <= 0 && st_sh == SFM_OK) {
+      // no iteration: the reference still returns R(q0) (campose:458)
+      int st = cam_prepare(params, &cam);
+      if (st != SFM_OK) st_sh = st;
+    }
+    for (int k = 0; k < 9; ++k) R_out[9 * view + k] = cam.R[k];
+    for (int k = 0; k < 3; ++k) C_out[3 * view + k] = params[k];
+    status[view] = st_sh;
+  }
+}
+
+static int first_bad(const std::vector<int>& st) {
+  for (size_t i = 0; i < st.size(); ++i)
+    if (st[i] != SFM_OK) return st[i];
+  return SFM_OK;
+}
+
+}  // namespace sfm
+
+using namespace sfm;
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int sfm_version(void) { return 100; }
+
+const char* sfm_last_error(void) { return g_err; }
+
+int sfm_init(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_error("no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    return SFM_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    set_error("device %d out of range (0..%d)", device, count - 1);
+    return SFM_E_NO_DEVICE;
+  }
+  Context& c = ctx();
+  if (c.inited && c.device == device) return SFM_OK;
+  if (c.inited) sfm_shutdown();
+  SFM_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SFM_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library ships gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+    return SFM_E_NO_DEVICE;
+  }
+  c.num_cus = prop.multiProcessorCount;
+  SFM_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.own_stream = true;
+  c.device = device;
+  c.inited = true;
+  return SFM_OK;
+}
+
+int sfm_shutdown(void) {
+  Context& c = ctx();
+  if (!c.inited) return SFM_OK;
+  (void)hipStreamSynchronize(c.stream);
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  c = Context();
+  return SFM_OK;
+}
+
+int sfm_set_stream(void* hip_stream) {
+  SFM_TRY(ensure_init());
+  Context& c = ctx();
+  SFM_HIP(hipStreamSynchronize(c.stream));
+  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  if (hip_stream == nullptr) {
+    SFM_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.own_stream = true;
+  } else {
+    c.stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c.own_stream = false;
+  }
+  return SFM_OK;
+}
+
+int sfm_synchronize(void) {
+  SFM_TRY(ensure_init());
+  SFM_HIP(hipStreamSynchronize(ctx().stream));
+  return SFM_OK;
+}
+
+int sfm_quat_to_rot(int n, const double* q, double* R, int* status) {
+  SFM_TRY(ensure_init());
+  if (n < 0) { set_error("sfm_quat_to_rot: n < 0"); return SFM_E_SHAPE; }
+  if (n == 0) return SFM_OK;
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dq, dR; DevBuf<int> dst;
+  SFM_TRY(dq.upload(q, 4 * (size_t)n, s)); SFM_TRY(dR.alloc(9 * (size_t)n)); SFM_TRY(dst.alloc(n));
+  quat_to_rot_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dq.p, dR.p, dst.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dR.download(R, 9 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_rot_to_quat(int n, const double* R, double* q, int* status) {
+  SFM_TRY(ensure_init());
+  if (n < 0) { set_error("sfm_rot_to_quat: n < 0"); return SFM_E_SHAPE; }
+  if (n == 0) return SFM_OK;
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dq, dR; DevBuf<int> dst;
+  SFM_TRY(dR.upload(R, 9 * (size_t)n, s)); SFM_TRY(dq.alloc(4 * (size_t)n)); SFM_TRY(dst.alloc(n));
+  rot_to_quat_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dR.p, dq.p, dst.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dq.download(q, 4 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_jac_cam(int n, const double* R, const double* C, const double* X, int quirks, double* Jp, int* status) {
+  SFM_TRY(ensure_init());
+  if (n < 0) { set_error("sfm_jac_cam: n < 0"); return SFM_E_SHAPE; }
+  if (n == 0) return SFM_OK;
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dR, dC, dX, dJ; DevBuf<int> dst;
+  SFM_TRY(dR.upload(R, 9 * (size_t)n, s)); SFM_TRY(dC.upload(C, 3 * (size_t)n, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s));
+  SFM_TRY(dJ.alloc(14 * (size_t)n)); SFM_TRY(dst.alloc(n));
+  jac_cam_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dR.p, dC.p, dX.p, quirks, dJ.p, dst.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dJ.download(Jp, 14 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_jac_pt(int n, int n_views, const double* projs, const double* X, double* Jx) {
+  SFM_TRY(ensure_init());
+  if (n < 0 || n_views < 1) { set_error("sfm_jac_pt: bad sizes n=%d n_views=%d", n, n_views); return SFM_E_SHAPE; }
+  if (n == 0) return SFM_OK;
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dP, dX, dJ;
+  SFM_TRY(dP.upload(projs, 12 * (size_t)n * n_views, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s));
+  SFM_TRY(dJ.alloc(6 * (size_t)n * n_views));
+  jac_pt_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, n_views, dP.p, dX.p, dJ.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dJ.download(Jx, 6 * (size_t)n * n_views, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_tri_nonlinear(int m, int n_views, const double* projs, const double* uv, const double* X_in, double lambda,
+                      int iters, double* X_out) {
+  SFM_TRY(ensure_init());
+  if (m < 0 || n_views < 1 || iters < 0) {
+    set_error("sfm_tri_nonlinear: bad sizes m=%d n_views=%d iters=%d", m, n_views, iters);
+    return SFM_E_SHAPE;
+  }
+  if (m == 0) return SFM_OK;
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dP, dUV, dX, dO;
+  SFM_TRY(dP.upload(projs, 12 * (size_t)n_views, s));
+  SFM_TRY(dUV.upload(uv, 2 * (size_t)n_views * m, s));
+  SFM_TRY(dX.upload(X_in, 4 * (size_t)m, s));
+  SFM_TRY(dO.alloc(4 * (size_t)m));
+  const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
+  tri_nonlinear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dX.p, lambda, iters, dO.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
+                            const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
+                            double* R_out, double* C_out, int* status) {
+  SFM_TRY(ensure_init());
+  if (n_views < 0 || total < 0 || iters < 0) {
+    set_error("sfm_pnp_nonlinear_batch: bad sizes n_views=%d total=%d iters=%d", n_views, total, iters);
+    return SFM_E_SHAPE;
+  }
+  if (n_views == 0) return SFM_OK;
+  if (offsets[0] != 0 || offsets[n_views] != total) { set_error("sfm_pnp_nonlinear_batch: offsets do not span [0,total]"); return SFM_E_SHAPE; }
+  for (int v = 0; v < n_views; ++v)
+    if (offsets[v + 1] < offsets[v]) { set_error("sfm_pnp_nonlinear_batch: offsets not monotone"); return SFM_E_SHAPE; }
+  hipStream_t s = ctx().stream;
+  DevBuf<int> dOff, dSt;
+  DevBuf<double> dUV, dX, dK, dR0, dC0, dR, dC;
+  SFM_TRY(dOff.upload(offsets, (size_t)n_views + 1, s));
+  SFM_TRY(dUV.upload(uv_pix, 3 * (size_t)total, s)); SFM_TRY(dX.upload(X, 4 * (size_t)total, s));
+  SFM_TRY(dK.upload(K, 9 * (size_t)n_views, s)); SFM_TRY(dR0.upload(R0, 9 * (size_t)n_views, s));
+  SFM_TRY(dC0.upload(C0, 3 * (size_t)n_views, s));
+  SFM_TRY(dR.alloc(9 * (size_t)n_views)); SFM_TRY(dC.alloc(3 * (size_t)n_views)); SFM_TRY(dSt.alloc(n_views));
+  pnp_nonlinear_kernel<<<n_views, 256, 0, s>>>(dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks,
+                                               dR.p, dC.p, dSt.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
+  SFM_TRY(dSt.download(status, n_views, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_pnp_nonlinear(int n, const double* uv_pix, const double* X, const double K[9], const double R0[9],
+                      const double C0[3], double lambda, int iters, int quirks, double R_out[9], double C_out[3]) {
+  if (n < 0) { set_error("sfm_pnp_nonlinear: n < 0"); return SFM_E_SHAPE; }
+  int offsets[2] = {0, n};
+  int st = SFM_OK;
+  SFM_TRY(sfm_pnp_nonlinear_batch(1, offsets, n, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, &st));
+  if (st != SFM_OK) set_error("sfm_pnp_nonlinear: rotation check failed on device (status %d)", st);
+  return st;
+}
+
+}  // extern "C"

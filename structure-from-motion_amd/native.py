@@ -1,0 +1,299 @@
+"""ctypes binding of the C-ABI in include/sfm_hip.h (libsfm_hip.so, gfx950).
+
+There is no CPU fallback: ``load()`` raises if the library is missing, and every compute call
+raises if no MI355X is visible.  Status codes map back to the exceptions the reference raises
+(``ValueError`` for bad shapes / invalid rotations, utils.py:43-51, 93-95).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsfm_hip.so")
+
+OK = 0
+E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE = -1, -2, -3, -4, -5, -6, -7
+Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
+SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA = 0, 1, 2
+OPT_SCHUR, OPT_TIMING = 1, 2
+K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub")
+
+# every symbol include/sfm_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "sfm_version", "sfm_init", "sfm_shutdown", "sfm_set_stream", "sfm_synchronize", "sfm_last_error",
+    "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
+    "sfm_tri_nonlinear", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
+    "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
+    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing",
+    "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
+    "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
+)
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class SfmHipError(RuntimeError):
+    """HIP / device / handle failures (no reference counterpart)."""
+
+
+def load():
+    """Load libsfm_hip.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SfmHipError(
+            "libsfm_hip.so not found at %s — build it with `make -C %s` (there is no CPU fallback)"
+            % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sfm_last_error.restype = ctypes.c_char_p
+    lib.sfm_set_stream.argtypes = [ctypes.c_void_p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name != "sfm_last_error":
+            fn.restype = ctypes.c_int
+    lib.sfm_ba_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp,
+                                  ctypes.POINTER(ctypes.c_void_p)]
+    for name in ("sfm_ba_destroy",):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.sfm_ba_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.sfm_ba_set_state.argtypes = [ctypes.c_void_p, _dp, _dp]
+    lib.sfm_ba_get_state.argtypes = [ctypes.c_void_p, _dp, _dp]
+    lib.sfm_ba_iterate.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    lib.sfm_ba_linearize_reduce.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sfm_ba_solve_update.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sfm_ba_kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, _ip]
+    lib.sfm_ba_reset_timing.argtypes = [ctypes.c_void_p]
+    lib.sfm_ba_reduced_buffer.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                          ctypes.POINTER(ctypes.c_int64), _ip]
+    lib.sfm_ba_bind_reduced_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    lib.sfm_ba_solve.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp, _dp,
+                                 ctypes.c_double, ctypes.c_int, ctypes.c_int]
+    lib.sfm_ba_residual_jacobian.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp, _dp,
+                                             ctypes.c_int, _dp, _dp, _dp]
+    lib.sfm_ba_reduced_system.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp, _dp,
+                                          ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
+    lib.sfm_tri_nonlinear.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int, _dp]
+    lib.sfm_pnp_nonlinear.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int,
+                                      ctypes.c_int, _dp, _dp]
+    lib.sfm_pnp_nonlinear_batch.argtypes = [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp, _dp, _dp,
+                                            ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp, _ip]
+    lib.sfm_quat_to_rot.argtypes = [ctypes.c_int, _dp, _dp, _ip]
+    lib.sfm_rot_to_quat.argtypes = [ctypes.c_int, _dp, _dp, _ip]
+    lib.sfm_jac_cam.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _ip]
+    lib.sfm_jac_pt.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sfm_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    """Map a C-ABI status to the exception the reference would raise."""
+    if status == OK:
+        return
+    msg = last_error()
+    if status == E_BAD_ROTATION:
+        raise ValueError("convert_quaternion_to_rotation : Invalid output rotation matrix (%s)" % msg)
+    if status == E_QW_ZERO:
+        raise ValueError("convert_rotation_to_quaternion : Invalid output qw (%s)" % msg)
+    if status == E_SQRT_DOMAIN:
+        raise ValueError("math domain error (%s)" % msg)
+    if status == E_SHAPE:
+        raise ValueError(msg)
+    raise SfmHipError("libsfm_hip status %d: %s" % (status, msg))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def init(device=0):
+    check(load().sfm_init(int(device)))
+
+
+def set_stream(stream_ptr):
+    check(load().sfm_set_stream(ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def synchronize():
+    check(load().sfm_synchronize())
+
+
+# ------------------------------------------------------------------------------------------------
+def quat_to_rot(q):
+    q = f64(q).reshape(-1, 4)
+    n = q.shape[0]
+    rot = np.empty((n, 3, 3)); st = np.empty(n, dtype=np.int32)
+    check(load().sfm_quat_to_rot(n, dptr(q), dptr(rot), iptr(st)))
+    return rot, st
+
+
+def rot_to_quat(rot):
+    rot = f64(rot).reshape(-1, 3, 3)
+    n = rot.shape[0]
+    q = np.empty((n, 4)); st = np.empty(n, dtype=np.int32)
+    check(load().sfm_rot_to_quat(n, dptr(rot), dptr(q), iptr(st)))
+    return q, st
+
+
+def jac_cam(rot, loc, pts_h, quirks=QUIRKS_REFERENCE):
+    rot = f64(rot).reshape(-1, 3, 3); loc = f64(loc).reshape(-1, 3); pts_h = f64(pts_h).reshape(-1, 4)
+    n = rot.shape[0]
+    jp = np.empty((n, 2, 7)); st = np.empty(n, dtype=np.int32)
+    check(load().sfm_jac_cam(n, dptr(rot), dptr(loc), dptr(pts_h), quirks, dptr(jp), iptr(st)))
+    return jp, st
+
+
+def jac_pt(projs, pts_h):
+    projs = f64(projs); pts_h = f64(pts_h).reshape(-1, 4)
+    n, nv = projs.shape[0], projs.shape[1]
+    jx = np.empty((n, 2 * nv, 3))
+    check(load().sfm_jac_pt(n, nv, dptr(projs), dptr(pts_h), dptr(jx)))
+    return jx
+
+
+def tri_nonlinear(projs, uv, x_in, lam, iters):
+    """projs (V,3,4); uv (V,2,m); x_in (4,m) -> (4,m)."""
+    projs = f64(projs); uv = f64(uv); x_in = f64(x_in)
+    nv, m = projs.shape[0], x_in.shape[1]
+    out = np.empty((4, m))
+    check(load().sfm_tri_nonlinear(m, nv, dptr(projs), dptr(uv), dptr(x_in), float(lam), int(iters), dptr(out)))
+    return out
+
+
+def pnp_nonlinear(uv_pix, pts_h, intrinsic, rot0, loc0, lam, iters, quirks=QUIRKS_REFERENCE):
+    uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic); rot0 = f64(rot0); loc0 = f64(loc0).reshape(3)
+    n = uv_pix.shape[1]
+    rot = np.empty((3, 3)); loc = np.empty(3)
+    check(load().sfm_pnp_nonlinear(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), dptr(rot0), dptr(loc0),
+                                   float(lam), int(iters), int(quirks), dptr(rot), dptr(loc)))
+    return rot, loc.reshape(3, 1)
+
+
+def pnp_nonlinear_batch(offsets, uv_pix, pts_h, intrinsics, rot0, loc0, lam, iters, quirks=QUIRKS_REFERENCE):
+    offsets = i32(offsets); uv_pix = f64(uv_pix); pts_h = f64(pts_h)
+    intrinsics = f64(intrinsics).reshape(-1, 3, 3); rot0 = f64(rot0).reshape(-1, 3, 3); loc0 = f64(loc0).reshape(-1, 3)
+    nv = offsets.shape[0] - 1
+    total = uv_pix.shape[1]
+    rot = np.empty((nv, 3, 3)); loc = np.empty((nv, 3)); st = np.empty(nv, dtype=np.int32)
+    check(load().sfm_pnp_nonlinear_batch(nv, iptr(offsets), total, dptr(uv_pix), dptr(pts_h), dptr(intrinsics),
+                                         dptr(rot0), dptr(loc0), float(lam), int(iters), int(quirks),
+                                         dptr(rot), dptr(loc), iptr(st)))
+    return rot, loc, st
+
+
+def ba_residual_jacobian(n_cams, pt_ptr, cam_idx, uv_norm, cams, pts, quirks=QUIRKS_REFERENCE):
+    pt_ptr = i32(pt_ptr); cam_idx = i32(cam_idx); uv_norm = f64(uv_norm); cams = f64(cams); pts = f64(pts)
+    n, m = pt_ptr.shape[0] - 1, cam_idx.shape[0]
+    r = np.empty((m, 2)); jp = np.empty((m, 2, 7)); jx = np.empty((m, 2, 3))
+    check(load().sfm_ba_residual_jacobian(n_cams, n, m, iptr(pt_ptr), iptr(cam_idx), dptr(uv_norm), dptr(cams),
+                                          dptr(pts), quirks, dptr(r), dptr(jp), dptr(jx)))
+    return r, jp, jx
+
+
+def ba_reduced_system(n_cams, pt_ptr, cam_idx, uv_norm, cams, pts, lam, quirks=QUIRKS_REFERENCE,
+                      schur_mode=SCHUR_AUTO):
+    pt_ptr = i32(pt_ptr); cam_idx = i32(cam_idx); uv_norm = f64(uv_norm); cams = f64(cams); pts = f64(pts)
+    n, m = pt_ptr.shape[0] - 1, cam_idx.shape[0]
+    s = np.empty((7 * n_cams, 7 * n_cams)); rhs = np.empty(7 * n_cams)
+    check(load().sfm_ba_reduced_system(n_cams, n, m, iptr(pt_ptr), iptr(cam_idx), dptr(uv_norm), dptr(cams),
+                                       dptr(pts), float(lam), quirks, schur_mode, dptr(s), dptr(rhs)))
+    return s, rhs
+
+
+def ba_solve(n_cams, pt_ptr, cam_idx, uv_norm, cams, pts, lam, iters, quirks=QUIRKS_REFERENCE):
+    pt_ptr = i32(pt_ptr); cam_idx = i32(cam_idx); uv_norm = f64(uv_norm)
+    cams = np.array(cams, dtype=np.float64, order="C", copy=True).reshape(-1, 7)
+    pts = np.array(pts, dtype=np.float64, order="C", copy=True)
+    n, m = pt_ptr.shape[0] - 1, cam_idx.shape[0]
+    check(load().sfm_ba_solve(n_cams, n, m, iptr(pt_ptr), iptr(cam_idx), dptr(uv_norm), dptr(cams), dptr(pts),
+                              float(lam), int(iters), int(quirks)))
+    return cams, pts
+
+
+class BaProblem:
+    """Device-resident BA problem (sfm_ba_create ... sfm_ba_destroy)."""
+
+    def __init__(self, n_cams, pt_ptr, cam_idx, uv_norm):
+        self._lib = load()
+        pt_ptr = i32(pt_ptr); cam_idx = i32(cam_idx); uv_norm = f64(uv_norm)
+        self.n_cams = int(n_cams)
+        self.n_pts = pt_ptr.shape[0] - 1
+        self.n_obs = cam_idx.shape[0]
+        if uv_norm.shape != (2, self.n_obs):
+            raise ValueError("uv_norm must be (2, M)")
+        h = ctypes.c_void_p()
+        check(self._lib.sfm_ba_create(self.n_cams, self.n_pts, self.n_obs, iptr(pt_ptr), iptr(cam_idx),
+                                      dptr(uv_norm), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfm_ba_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, option, value):
+        check(self._lib.sfm_ba_set_option(self._h, option, value))
+
+    def set_state(self, cams, pts):
+        cams = f64(cams).reshape(-1, 7); pts = f64(pts)
+        if cams.shape[0] != self.n_cams or pts.shape != (3, self.n_pts):
+            raise ValueError("state shapes do not match the problem")
+        check(self._lib.sfm_ba_set_state(self._h, dptr(cams), dptr(pts)))
+
+    def iterate(self, lam, iters, quirks=QUIRKS_REFERENCE):
+        check(self._lib.sfm_ba_iterate(self._h, float(lam), int(iters), int(quirks)))
+
+    def linearize_reduce(self, lam, quirks=QUIRKS_REFERENCE):
+        check(self._lib.sfm_ba_linearize_reduce(self._h, float(lam), int(quirks)))
+
+    def solve_update(self, lam, quirks=QUIRKS_REFERENCE):
+        check(self._lib.sfm_ba_solve_update(self._h, float(lam), int(quirks)))
+
+    def get_state(self):
+        cams = np.empty((self.n_cams, 7)); pts = np.empty((3, self.n_pts))
+        check(self._lib.sfm_ba_get_state(self._h, dptr(cams), dptr(pts)))
+        return cams, pts
+
+    def reduced_buffer(self):
+        ptr = ctypes.c_void_p(); n = ctypes.c_int64(); ld = ctypes.c_int()
+        check(self._lib.sfm_ba_reduced_buffer(self._h, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(ld)))
+        return ptr.value, n.value, ld.value
+
+    def bind_reduced_buffer(self, device_ptr, n_doubles):
+        check(self._lib.sfm_ba_bind_reduced_buffer(self._h, ctypes.c_void_p(device_ptr), int(n_doubles)))
+
+    def kernel_time(self, kernel_id):
+        ms = ctypes.c_double(); n = ctypes.c_int()
+        check(self._lib.sfm_ba_kernel_time(self._h, kernel_id, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def reset_timing(self):
+        check(self._lib.sfm_ba_reset_timing(self._h))

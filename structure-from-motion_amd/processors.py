@@ -1,0 +1,259 @@
+"""Drop-in mirrors of the reference's ``*_processor`` classes for the nonlinear-refinement hot path.
+
+Same method names, argument meaning, defaults, return shapes, in-place semantics, prints and
+exceptions as the reference; the arithmetic runs in libsfm_hip.so on an MI355X.
+
+Two ways to use them:
+
+* as **mixins in front of the reference classes** — the reference keeps its front end, linear
+  solvers and state machine, the hot path is overridden::
+
+      class TriangulationProcessor(HipTriangulationMixin, triangulation_processor.TriangulationProcessor): pass
+      class CamposeProcessor(HipCamposeMixin, campose_processor.CamposeProcessor): pass
+      class BaProcessor(HipBaMixin, ba_processor.BaProcessor): pass
+
+* as the **standalone classes** below (``HipTriangulationProcessor`` ...), which carry the
+  constructor state of the reference classes and are what the tests drive.
+
+Reference interfaces mirrored (file:line in the reference repo):
+  TriangulationProcessor.nonlinear_triangulate / construct_jacobian_matrix / triangulate
+      triangulation_processor.py:160-234 / 237-271 / 31-88
+  CamposeProcessor.nonlinear_estimate_cam_pose_pnp / construct_jacobian_matrix / estimate_cam_pose_pnp
+      campose_processor.py:308-459 / 462-482 / 192-246
+  BaProcessor.__execute_bundle_adjustment          ba_processor.py:274-439
+"""
+import logging
+import math
+
+import numpy as np
+
+from . import native
+from .geometry import (pack_camera, quaternion_to_rotation, quaternion_to_rotation_unchecked)
+from .observations import build_observations, gather_normalised_keys
+
+
+# ------------------------------------------------------------------------------------------------
+class HipTriangulationMixin:
+    """Hot-path methods of TriangulationProcessor (triangulation_processor.py:7-309)."""
+
+    def nonlinear_triangulate(self, init_3d_pts, projs, matched_pairs,
+                              damping_factor=None, iteration=None):
+        # falsy -> instance default, exactly like the reference (tri:200-203, quirk Q4)
+        if not damping_factor:
+            damping_factor = self.damping_factor
+        if not iteration:
+            iteration = self.iteration
+        num_pts = matched_pairs[0].shape[1]
+        num_views = len(projs)
+        init = np.ascontiguousarray(np.asarray(init_3d_pts), dtype=np.float64)
+        if num_pts == 0:
+            return np.copy(init)
+        uv = np.empty((num_views, 2, num_pts), dtype=np.float64)
+        for v in range(num_views):
+            uv[v] = np.asarray(matched_pairs[v])[0:2, :]
+        projs_arr = np.stack([np.asarray(p, dtype=np.float64).reshape(3, 4) for p in projs])
+        # the reference iterates over matched_pairs[0].shape[1] columns of a copy of init_3d_pts
+        out = np.copy(init)
+        out[:, :num_pts] = native.tri_nonlinear(projs_arr, uv, init[:, :num_pts], damping_factor, iteration)
+        return out
+
+    def construct_jacobian_matrix(self, tri_3d_pt, projs, num_views):
+        projs_arr = np.stack([np.asarray(p, dtype=np.float64).reshape(3, 4) for p in projs[:num_views]])
+        jx = native.jac_pt(projs_arr[None], np.asarray(tri_3d_pt, dtype=np.float64).reshape(1, 4))
+        return jx[0]
+
+    def triangulate(self, projs, matched_pairs, damping_factor=None, iteration=None):
+        if not damping_factor:
+            damping_factor = self.damping_factor
+        if not iteration:
+            iteration = self.iteration
+        num_projs = len(projs)
+        num_views = len(matched_pairs)
+        if num_projs != num_views:
+            logging.warning('%s : the numbers of views and of projections are different, %d and %d',
+                            self.__class__.__name__, num_views, num_projs)
+            raise ValueError("different numbers of views and projections : {} - {}".format(num_views, num_projs))
+        if num_projs < 2:
+            logging.warning('%s : insufficient projections, %d', self.__class__.__name__, num_projs)
+            raise ValueError("insufficient projections : {}".format(num_projs))
+        init_3d_pts = self.linear_triangulate(projs, matched_pairs)
+        return self.nonlinear_triangulate(init_3d_pts, projs, matched_pairs, damping_factor, iteration)
+
+
+class HipTriangulationProcessor(HipTriangulationMixin):
+    """Standalone TriangulationProcessor: constructor state of triangulation_processor.py:12-28.
+
+    ``linear_triangulate`` (the DLT initialiser, tri:91-157) is host-side NumPy here: it is an
+    adjacent row of the scope table, not part of the device hot path."""
+
+    def __init__(self, damping_factor=0.5, iteration=100):
+        self.damping_factor = damping_factor
+        self.iteration = iteration
+        self.tri_pts = None
+
+    def add_tri_pt(self, tri_pt):
+        if not np.any(self.tri_pts):
+            self.tri_pts = tri_pt
+        else:
+            self.tri_pts = np.hstack((self.tri_pts, tri_pt))
+
+    def linear_triangulate(self, projs, matched_pairs):
+        if len(matched_pairs) != len(projs) != 2:       # sic: chained comparison of the reference (Q12)
+            print('{}:{} - num of projs {} and matched pairs {} need to be 2'.format(
+                self.__class__.__name__, 'linear_triangulate', len(projs), len(matched_pairs)))
+            return None
+        if matched_pairs[0].shape[1] != matched_pairs[1].shape[1]:
+            print('{}:{} - matched pairs number does not match {} vs {}'.format(
+                self.__class__.__name__, 'linear_triangulate',
+                matched_pairs[0].shape[1], matched_pairs[1].shape[1]))
+            return None
+        num_views = len(matched_pairs)
+        num_pts = matched_pairs[0].shape[1]
+        a = np.zeros((num_pts, 2 * num_views, 4))
+        for v in range(num_views):
+            proj = np.asarray(projs[v], dtype=np.float64)
+            u = np.asarray(matched_pairs[v])[0, :]
+            w = np.asarray(matched_pairs[v])[1, :]
+            a[:, 2 * v, :] = u[:, None] * proj[2:3, :] - proj[0:1, :]
+            a[:, 2 * v + 1, :] = w[:, None] * proj[2:3, :] - proj[1:2, :]
+        out = np.zeros((4, num_pts))
+        out[3, :] = 1.0
+        if num_pts:
+            _, _, vh = np.linalg.svd(a)
+            x = vh[:, -1, :]
+            out[:, :] = (x / x[:, 3:4]).T
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class HipCamposeMixin:
+    """Hot-path methods of CamposeProcessor (campose_processor.py:11-808)."""
+
+    quirk_flags = native.QUIRKS_REFERENCE        # bug-compatible by default
+
+    def nonlinear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat,
+                                        init_rot, init_loc, damping_factor=None, iteration=None):
+        if not damping_factor:
+            damping_factor = self.damping_factor
+        if not iteration:
+            iteration = self.iteration
+        if key_2d_pts.shape[1] != tri_3d_pts.shape[1]:
+            logging.warning('%s : different numbers of key points and of triangulated points',
+                            self.__class__.__name__)
+            raise ValueError("key pts num - triangulated pts num : {} - {}"
+                             .format(key_2d_pts.shape[1], tri_3d_pts.shape[1]))
+        rot, loc = native.pnp_nonlinear(key_2d_pts, tri_3d_pts, intrinsic_mat, init_rot, init_loc,
+                                        damping_factor, iteration, self.quirk_flags)
+        return rot, loc
+
+    def construct_jacobian_matrix(self, rot, loc, pt_3d):
+        jp, st = native.jac_cam(np.asarray(rot, dtype=np.float64).reshape(1, 3, 3),
+                                np.asarray(loc, dtype=np.float64).reshape(1, 3),
+                                np.asarray(pt_3d, dtype=np.float64).reshape(1, 4), self.quirk_flags)
+        native.check(int(st[0]))
+        return jp[0]
+
+    def estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat,
+                              ransac_config=None, damping_factor=None, iteration=None):
+        if not ransac_config:
+            ransac_config = self.ransac_config
+        if not damping_factor:
+            damping_factor = self.damping_factor
+        if not iteration:
+            iteration = self.iteration
+        inlier_indices, ini_rot, ini_loc = self.linear_estimate_cam_pose_pnp(
+            key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
+        ref_rot, ref_loc = self.nonlinear_estimate_cam_pose_pnp(
+            key_2d_pts[:, inlier_indices], tri_3d_pts[:, inlier_indices], intrinsic_mat,
+            ini_rot, ini_loc, damping_factor, iteration)
+        return inlier_indices, ref_rot, ref_loc
+
+
+class HipCamposeProcessor(HipCamposeMixin):
+    """Standalone CamposeProcessor (constructor of campose_processor.py:12-26).  The RANSAC DLT
+    initialiser ``linear_estimate_cam_pose_pnp`` (campose:249-305) is outside this path (SURVEY.md
+    section 8 f3); supply one (e.g. the reference's bound method) via ``linear_estimator``."""
+
+    def __init__(self, ransac_config, damping_factor, iteration, linear_estimator=None):
+        self.ransac_config = ransac_config
+        self.damping_factor = damping_factor
+        self.iteration = iteration
+        self._linear_estimator = linear_estimator
+
+    def linear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config=None):
+        if self._linear_estimator is None:
+            raise NotImplementedError(
+                "linear (RANSAC DLT) PnP is not part of the device hot path; pass linear_estimator=")
+        return self._linear_estimator(key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
+
+
+# ------------------------------------------------------------------------------------------------
+class HipBaMixin:
+    """``BaProcessor.__execute_bundle_adjustment`` (ba_processor.py:274-439) on the device.
+
+    Reads ``self.view_processor.view_list`` (``.rot/.loc/.k/.key_pts[i].pt``),
+    ``self.key_tracker.track_list[i].table``, ``self.tri_processor.tri_pts``, ``self.iteration``,
+    ``self.damping_factor``; writes the refined poses back through ``view.update_cam_pose`` and the
+    refined points into ``tri_pts[0:3, :]`` in place; prints the reference's DEBUG lines."""
+
+    ba_quirk_flags = native.QUIRKS_REFERENCE
+    ba_verbose = True          # the reference prints unconditionally (ba:418-439)
+
+    def execute_bundle_adjustment(self):
+        views = self.view_processor.view_list
+        tri_pts = self.tri_processor.tri_pts
+        view_num = len(views)
+        tri_num = tri_pts.shape[1]
+
+        init_cam_poses = np.zeros((view_num, 7))
+        for view_idx in range(view_num):
+            init_cam_poses[view_idx] = pack_camera(views[view_idx].rot, views[view_idx].loc)   # ba:285-288
+        init_tri_pts = np.ascontiguousarray(tri_pts[0:3, :], dtype=np.float64)                 # ba:292-294
+
+        rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
+        pt_ptr, cam_idx, _pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
+        uv_norm = gather_normalised_keys(views, cam_idx, key_idx)                              # ba:339-342
+
+        cams, pts = native.ba_solve(view_num, pt_ptr, cam_idx, uv_norm, init_cam_poses, init_tri_pts,
+                                    self.damping_factor, self.iteration, self.ba_quirk_flags)
+
+        for view_idx in range(view_num):                                                       # ba:409-413
+            loc = cams[view_idx, 0:3].reshape(3, 1).copy()
+            rot = quaternion_to_rotation(cams[view_idx, 3:7].reshape(4, 1))
+            views[view_idx].update_cam_pose(rot, loc)
+        tri_pts[0:3, :] = pts                                                                  # ba:415-416
+
+        if self.ba_verbose:                                                                    # ba:418-439
+            from scipy.spatial.transform import Rotation
+            for view_idx in range(view_num):
+                diff_loc = math.sqrt(np.sum(np.square(init_cam_poses[view_idx, 0:3] - cams[view_idx, 0:3])))
+                print('DEBUG: {}-th view loc distance changes {} unit'.format(view_idx, diff_loc))
+                init_rot = quaternion_to_rotation_unchecked(init_cam_poses[view_idx, 3:7])
+                refi_rot = quaternion_to_rotation_unchecked(cams[view_idx, 3:7])
+                init_angle = Rotation.from_matrix(init_rot).as_euler('zyx', degrees=True)
+                refi_angle = Rotation.from_matrix(refi_rot).as_euler('zyx', degrees=True)
+                print('DEBUG: {}-th view angles changes {} degree'.format(view_idx, np.abs(init_angle - refi_angle)))
+            moved = np.sqrt(np.sum(np.square(init_tri_pts - pts), axis=0))
+            for tri_idx in np.flatnonzero(moved >= 5):
+                print('DEBUG: {}-th pt loc changes more than 5 unit, {} unit'.format(tri_idx, moved[tri_idx]))
+
+    # the reference calls the name-mangled private method (ba_processor.py:267)
+    _BaProcessor__execute_bundle_adjustment = execute_bundle_adjustment
+
+
+class HipBaProcessor(HipBaMixin):
+    """Standalone holder of the BaProcessor constructor state (ba_processor.py:22-40).  The
+    incremental state machine ``process`` (ba:43-270) needs the OpenCV front end and stays in the
+    reference; use ``class BaProcessor(HipBaMixin, ba_processor.BaProcessor)`` for the full pipeline."""
+
+    def __init__(self, view_processor, key_tracker, epi_processor, tri_processor, campose_processor,
+                 filter_size=10, iteration=3, damping_factor=5):
+        self.curr_data_idx = 0
+        self.filter_size = filter_size
+        self.iteration = iteration
+        self.damping_factor = damping_factor
+        self.view_processor = view_processor
+        self.key_tracker = key_tracker
+        self.epi_processor = epi_processor
+        self.tri_processor = tri_processor
+        self.campose_processor = campose_processor

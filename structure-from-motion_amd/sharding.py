@@ -1,0 +1,102 @@
+"""Point-range sharding of bundle adjustment across ranks (one process per GPU).
+
+Given the cameras, points are independent: each rank owns a contiguous range of points (with all
+their observations), forms its partial reduced camera system ``[S | rhs]`` locally, and ONE
+all-reduce (SUM, float64) per iteration makes the full system available everywhere; every rank
+then performs the identical reduced solve and back-substitutes its own points (SURVEY.md
+section 8(e)).  The reference has no distributed code; this is new, specified by the algebra of
+ba_processor.py:376-406: ``A``, ``B D^-1 B^T``, ``ep`` and ``B D^-1 ex`` are sums over
+observations / points, so partial sums over disjoint point ranges add up to the full matrices.
+
+The collective is issued by the caller-supplied ``all_reduce`` (``torch.distributed.all_reduce``
+on RCCL for GPU ranks, gloo in the CPU tests); the engine that produces the partial system and
+consumes the reduced one is pluggable so the sharding logic is testable without a GPU.
+"""
+import numpy as np
+
+from . import native
+
+
+def shard_bounds(pt_ptr, world_size, weight="pairs"):
+    """Contiguous point ranges balanced by Schur-product cost: weight k(k+1)/2 per point for
+    ``"pairs"`` (camera pairs), k for ``"obs"``.  Returns ``bounds`` (world_size + 1,)."""
+    pt_ptr = np.asarray(pt_ptr, dtype=np.int64)
+    n_pts = pt_ptr.shape[0] - 1
+    k = np.diff(pt_ptr).astype(np.float64)
+    w = k * (k + 1) / 2 if weight == "pairs" else k
+    w = w + 1e-3                                  # empty tracks still cost a little; keeps ranges non-degenerate
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    targets = cum[-1] * np.arange(1, world_size) / world_size
+    inner = np.searchsorted(cum, targets, side="left")
+    bounds = np.concatenate(([0], inner, [n_pts])).astype(np.int64)
+    return np.maximum.accumulate(np.minimum(bounds, n_pts))
+
+
+def local_shard(pt_ptr, cam_idx, uv_norm, pts, bounds, rank):
+    """Slice the observation CSR, keys and points of one rank.  Returns
+    (pt_ptr_local, cam_idx_local, uv_local, pts_local, (p0, p1))."""
+    p0, p1 = int(bounds[rank]), int(bounds[rank + 1])
+    o0, o1 = int(pt_ptr[p0]), int(pt_ptr[p1])
+    ptr = (np.asarray(pt_ptr[p0:p1 + 1], dtype=np.int64) - o0).astype(np.int32)
+    return (ptr, np.ascontiguousarray(cam_idx[o0:o1], dtype=np.int32),
+            np.ascontiguousarray(np.asarray(uv_norm)[:, o0:o1], dtype=np.float64),
+            np.ascontiguousarray(np.asarray(pts)[:, p0:p1], dtype=np.float64), (p0, p1))
+
+
+class HipShardEngine:
+    """One rank's device-resident shard.  The reduced buffer is a torch tensor so that
+    ``torch.distributed.all_reduce`` (RCCL) can run on it in place; kernels and the collective
+    share torch's current stream."""
+
+    def __init__(self, n_cams, pt_ptr_local, cam_idx_local, uv_local, device):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        native.init(self.device.index or 0)
+        # a dedicated (non-null) torch stream: the library launches on it and the collective is issued
+        # under it, so RCCL's internal stream waits for the kernels and vice versa
+        self.stream = torch.cuda.Stream(self.device)
+        native.set_stream(self.stream.cuda_stream)
+        self.prob = native.BaProblem(n_cams, pt_ptr_local, cam_idx_local, uv_local)
+        _ptr, n, self.ld = self.prob.reduced_buffer()
+        self.reduced = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.prob.bind_reduced_buffer(self.reduced.data_ptr(), n)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def set_state(self, cams, pts_local):
+        self.prob.set_state(cams, pts_local)
+
+    def linearize_reduce(self, lam, quirks=native.QUIRKS_REFERENCE):
+        self.prob.linearize_reduce(lam, quirks)
+        return self.reduced
+
+    def solve_update(self, lam, quirks=native.QUIRKS_REFERENCE):
+        self.prob.solve_update(lam, quirks)
+
+    def get_state(self):
+        return self.prob.get_state()
+
+    def close(self):
+        self.prob.bind_reduced_buffer(0, 0)
+        self.prob.close()
+        native.set_stream(0)
+
+
+class ShardedBa:
+    """Damped Gauss-Newton BA over ``world_size`` ranks: engine.linearize_reduce -> all_reduce ->
+    engine.solve_update, ``iters`` times.  With world_size == 1 no collective is issued."""
+
+    def __init__(self, engine, all_reduce=None, world_size=1):
+        self.engine = engine
+        self.all_reduce = all_reduce
+        self.world_size = world_size
+
+    def iterate(self, lam, iters, quirks=native.QUIRKS_REFERENCE):
+        with self.engine.stream_context():
+            for _ in range(iters):
+                buf = self.engine.linearize_reduce(lam, quirks)
+                if self.world_size > 1:
+                    self.all_reduce(buf)
+                self.engine.solve_update(lam, quirks)

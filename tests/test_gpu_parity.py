@@ -1,0 +1,369 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs and against the golden fixtures captured from the reference.
+
+Tolerances: the contract (BASELINE.json north_star) is 1e-6 relative reprojection error; float64
+kernels with a different summation order agree far tighter, so vectors are held to 1e-9 relative
+(max-norm) and RMSE to 1e-9 relative, with the 1e-6 contract asserted separately.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def uv_norm_of(g):
+    kinv = np.linalg.inv(g["K"])
+    hom = np.vstack((g["uv_pix"], np.ones((1, g["uv_pix"].shape[1]))))
+    cam = kinv @ hom
+    return cam[0:2] / cam[2:3]
+
+
+# ---- unit hooks -------------------------------------------------------------------------------
+def test_jac_cam_golden(hip):
+    g = load_golden("g1_jac_cam.npz")
+    jp, st = hip.jac_cam(g["R"], g["C"], g["X"])
+    assert np.all(st == 0)
+    assert rel(jp, g["Jp"]) < 1e-11
+    worst = max(rel(a, b) for a, b in zip(jp, g["Jp"]))
+    assert worst < 1e-9
+
+
+def test_jac_pt_golden(hip):
+    g = load_golden("g2_jac_pt.npz")
+    jx = hip.jac_pt(g["projs"], g["X"])
+    assert rel(jx, g["Jx"]) < 1e-12
+
+
+def test_quaternion_helpers_golden(hip):
+    g = load_golden("g3_quat.npz")
+    q, st = hip.rot_to_quat(g["R"])
+    assert np.all(st == 0) and rel(q, g["q"]) < 1e-14
+    rot, st = hip.quat_to_rot(g["q"])
+    assert np.all(st == 0) and rel(rot, g["R_back"]) < 1e-14
+    # accept / reject set of verify_rotation_mat at its 1e-8 one-sided thresholds
+    _, st = hip.rot_to_quat(g["verify_cases"])
+    assert np.array_equal(st != hip.E_BAD_ROTATION, g["verify_verdict"])
+    _, st = hip.quat_to_rot(g["q_scaled"])
+    assert np.array_equal(st == 0, g["q_scaled_ok"])
+
+
+def test_rotation_error_statuses(hip):
+    bad = np.diag([1.0, 1.0, 1.0 + 1e-3])
+    _, st = hip.rot_to_quat(bad)
+    assert st[0] == hip.E_BAD_ROTATION
+    half_turn = np.diag([1.0, -1.0, -1.0])          # trace = -1 -> qw = 0
+    _, st = hip.rot_to_quat(half_turn)
+    assert st[0] in (hip.E_QW_ZERO, hip.E_SQRT_DOMAIN)
+
+
+# ---- nonlinear triangulation ---------------------------------------------------------------------
+def test_tri_known_answer(hip):
+    """triangulation_processor.py:415-473 literal case."""
+    g = load_golden("g4_tri.npz")
+    out = hip.tri_nonlinear(g["lit_projs"][0:2], g["lit_uv"][0:2, 0:2, :], g["lit_linear"], 0.5, 300)
+    assert rel(out, g["lit_whole"]) < TOL
+    assert np.allclose(out[:, 0], [-0.034700141239, -0.005983101498, 2.021981140992, 1.0], atol=1e-10)
+    out3 = hip.tri_nonlinear(g["lit_projs"], g["lit_uv"][:, 0:2, :], g["lit_linear"], 0.5, 50)
+    assert rel(out3, g["lit_three_view"]) < TOL
+
+
+def test_tri_opencv_fixture(hip):
+    g = load_golden("g4_tri.npz")
+    uv = g["cv_uv"][:, 0:2, :]
+    for key, lam, its in (("cv_its1", 0.5, 1), ("cv_its10", 0.5, 10), ("cv_lam10_its5", 10, 5), ("cv_its100", 0.5, 100)):
+        if key not in g.files:
+            continue
+        out = hip.tri_nonlinear(g["cv_projs"], uv, g["cv_init"], lam, its)
+        assert rel(out, g[key]) < TOL, key
+        assert np.array_equal(out[3], g["cv_init"][3])          # W row untouched
+
+
+@pytest.mark.parametrize("nv", [2, 3, 5])
+def test_tri_synthetic(hip, nv):
+    g = load_golden("g4_tri.npz")
+    out = hip.tri_nonlinear(g["syn%d_projs" % nv], g["syn%d_uv" % nv][:, 0:2, :], g["syn%d_init" % nv], 0.5, 20)
+    assert rel(out, g["syn%d_out" % nv]) < TOL
+
+
+def test_tri_large_vs_oracle_and_ragged_sizes(hip, oracle, sfm):
+    sc = sfm.scenes.make_scene(4, 5003, 1.0, seed=21)          # not a multiple of the block size
+    projs, uv = [], []
+    for c in range(4):
+        rot = sfm.geometry.quaternion_to_rotation(sc.cams_true[c, 3:7])
+        loc = sc.cams_true[c, 0:3].reshape(3, 1)
+        projs.append(sc.intrinsic @ np.hstack((rot.T, rot.T @ -loc)))
+        uv.append(sc.uv_pix[:, sc.cam_idx == c])
+    init = np.vstack((sc.pts_init, np.ones((1, sc.n_pts))))
+    got = hip.tri_nonlinear(np.stack(projs), np.stack(uv), init, 0.5, 30)
+    want = oracle.nonlinear_triangulate_vec(init, projs, uv, 0.5, 30)
+    assert rel(got, want) < TOL
+    # idempotence-style property at size: 0 iterations returns the input bit-exactly
+    same = hip.tri_nonlinear(np.stack(projs), np.stack(uv), init, 0.5, 0)
+    assert np.array_equal(same, init)
+    # empty input
+    assert hip.tri_nonlinear(np.stack(projs), np.zeros((4, 2, 0)), np.zeros((4, 0)), 0.5, 5).shape == (4, 0)
+
+
+# ---- nonlinear PnP -----------------------------------------------------------------------------
+def test_pnp_opencv_fixture(hip):
+    g = load_golden("g5_pnp.npz")
+    inl = g["inliers"]
+    uv, x = g["pts2d"][:, inl], g["pts3d"][:, inl]
+    for its in (1, 2, 10, 200):
+        if "C_its%d" % its not in g.files:
+            continue
+        r, c = hip.pnp_nonlinear(uv, x, g["K"], g["R0"], g["C0"], 5, its)
+        assert rel(r, g["R_its%d" % its]) < TOL, its
+        assert rel(c, g["C_its%d" % its]) < TOL, its
+    r, c = hip.pnp_nonlinear(uv, x, g["K"], g["R0"], g["C0"], 5, 200)
+    assert np.allclose(c[:, 0], [-1.690676720621, 0.054300873096, 0.658193978912], atol=1e-9)
+    assert np.linalg.norm(c - g["loc_truth"]) < 0.1          # the reference's own acceptance bound
+
+
+def test_pnp_quirk_modes_vs_oracle(hip, oracle):
+    g = load_golden("g5_pnp.npz")
+    uv, x = g["syn1_uv"], g["syn1_X"]
+    for quirks in (0, 1, 2, 3):
+        r, c = hip.pnp_nonlinear(uv, x, g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 15, quirks)
+        ro, co = oracle.nonlinear_pnp(uv, x, g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 15, quirks)
+        assert rel(r, ro) < TOL and rel(c, co) < TOL, quirks
+
+
+def test_pnp_batch_matches_single(hip):
+    g = load_golden("g5_pnp.npz")
+    uvs = [g["syn%d_uv" % c] for c in (1, 2, 3)]
+    xs = [g["syn%d_X" % c] for c in (1, 2, 3)]
+    offsets = np.cumsum([0] + [u.shape[1] for u in uvs]).astype(np.int32)
+    rot, loc, st = hip.pnp_nonlinear_batch(offsets, np.hstack(uvs), np.hstack(xs), np.stack([g["syn_K"]] * 3),
+                                           np.stack([g["syn%d_R0" % c] for c in (1, 2, 3)]),
+                                           np.stack([g["syn%d_C0" % c][:, 0] for c in (1, 2, 3)]), 5, 25)
+    assert np.all(st == 0)
+    for i, c in enumerate((1, 2, 3)):
+        assert rel(rot[i], g["syn%d_R" % c]) < TOL
+        assert rel(loc[i], g["syn%d_C" % c][:, 0]) < TOL
+
+
+def test_pnp_invalid_rotation_raises(hip):
+    g = load_golden("g5_pnp.npz")
+    bad = g["syn1_R0"] * 1.01
+    with pytest.raises(ValueError):
+        hip.pnp_nonlinear(g["syn1_uv"], g["syn1_X"], g["syn_K"], bad, g["syn1_C0"], 5, 3)
+
+
+# ---- bundle adjustment -----------------------------------------------------------------------------
+BA_CASES = ["3x50", "5x200v80", "6x120v60", "8x300v50"]
+
+
+@pytest.mark.parametrize("name", ["3x50", "5x200v80", "6x120v60"])
+def test_ba_residual_jacobian_golden(hip, name):
+    g = load_golden("g6_ba_%s.npz" % name)
+    r, jp, jx = hip.ba_residual_jacobian(g["cams_init"].shape[0], g["pt_ptr"], g["cam_idx"], uv_norm_of(g),
+                                         g["cams_init"], g["pts_init"])
+    assert rel(r, g["lin_r"]) < 1e-11
+    assert rel(jp, g["lin_Jp"]) < 1e-11
+    assert rel(jx, g["lin_Jx"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["3x50", "5x200v80", "6x120v60"])
+@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+def test_ba_reduced_system_golden(hip, name, mode):
+    g = load_golden("g6_ba_%s.npz" % name)
+    mode_id = hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA
+    s, rhs = hip.ba_reduced_system(g["cams_init"].shape[0], g["pt_ptr"], g["cam_idx"], uv_norm_of(g),
+                                   g["cams_init"], g["pts_init"], 5.0, schur_mode=mode_id)
+    assert rel(s, g["lin_S"]) < 1e-11
+    assert rel(rhs, g["lin_rhs"]) < 1e-10
+    assert np.array_equal(s, s.T)
+
+
+@pytest.mark.parametrize("name", BA_CASES)
+@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+def test_ba_iterations_golden(hip, name, mode):
+    """1, 2 and 3 iterations against the reference's own results."""
+    g = load_golden("g6_ba_%s.npz" % name)
+    uvn = uv_norm_of(g)
+    with hip.BaProblem(g["cams_init"].shape[0], g["pt_ptr"], g["cam_idx"], uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_state(g["cams_init"], g["pts_init"])
+        for it in (1, 2, 3):
+            prob.iterate(5.0, 1)
+            cams, pts = prob.get_state()
+            assert rel(cams, g["cams_it%d" % it]) < TOL, (name, it)
+            assert rel(pts, g["pts_it%d" % it]) < TOL, (name, it)
+
+
+def test_ba_config2_reference_golden(hip, sfm):
+    """BASELINE config 2 (5 x 2000 dense), 3 iterations, against the reference run (329 s on CPU)."""
+    g = load_golden("g6_ba_C2.npz")
+    cams, pts = hip.ba_solve(5, g["pt_ptr"], g["cam_idx"], uv_norm_of(g), g["cams_init"], g["pts_init"], 5.0, 3)
+    assert rel(cams, g["cams_it3"]) < TOL and rel(pts, g["pts_it3"]) < TOL
+    sc = sfm.scenes.make_config("C2", seed=0)
+    assert np.array_equal(sc.cam_idx, g["cam_idx"])
+    rm = sfm.scenes.reprojection_rmse(cams, pts, sc)
+    assert abs(rm - float(g["rmse_it3"])) / float(g["rmse_it3"]) < 1e-6       # the north-star contract
+    assert abs(rm - float(g["rmse_it3"])) / float(g["rmse_it3"]) < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+def test_ba_vs_oracle_midsize_ragged(hip, oracle, sfm, mode):
+    """20 cams x 3000 points at 30 % visibility: ragged tracks (2..~12), some longer than the lane group."""
+    sc = sfm.scenes.make_scene(20, 3001, 0.3, seed=8)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 3)
+        cams, pts = prob.get_state()
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    assert rel(cams, ocams) < TOL and rel(pts, opts) < TOL
+    r0 = sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc)
+    r3 = sfm.scenes.reprojection_rmse(cams, pts, sc)
+    ro = sfm.scenes.reprojection_rmse(ocams, opts, sc)
+    assert r3 < r0 and abs(r3 - ro) / ro < 1e-9
+
+
+def test_ba_config3_full_size_vs_oracle(hip, oracle, sfm):
+    """BASELINE config 3 (50 x 20 000 @ 60 %): one iteration against the block-sparse oracle plus
+    size-independent properties: RMSE decreases monotonically over 3 iterations, quaternions stay unit,
+    and the two Schur kernels agree."""
+    sc = sfm.scenes.make_config("C3", seed=0)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 1)
+    results = {}
+    for mode in (hip.SCHUR_MFMA, hip.SCHUR_PAIRS):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, mode)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 1)
+            cams1, pts1 = prob.get_state()
+            assert rel(cams1, ocams) < TOL and rel(pts1, opts) < TOL
+            rm = [sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc), sfm.scenes.reprojection_rmse(cams1, pts1, sc)]
+            for _ in range(2):
+                prob.iterate(5.0, 1)
+                c, p = prob.get_state()
+                rm.append(sfm.scenes.reprojection_rmse(c, p, sc))
+            assert all(b < a for a, b in zip(rm, rm[1:])), rm
+            assert np.allclose(np.linalg.norm(c[:, 3:7], axis=1), 1.0, atol=1e-14)
+            results[mode] = (c, p)
+    assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_PAIRS][0]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_PAIRS][1]) < TOL
+
+
+def test_ba_edge_cases(hip, oracle, sfm):
+    sc = sfm.scenes.make_scene(3, 40, 0.8, seed=2)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    # zero iterations: state returned bit-exactly
+    cams, pts = hip.ba_solve(3, sc.pt_ptr, sc.cam_idx, uvn, sc.cams_init, sc.pts_init, 5.0, 0)
+    assert np.array_equal(cams, sc.cams_init) and np.array_equal(pts, sc.pts_init)
+    # a point with no observation keeps its position (D_p = lambda I, ex = 0; ba:359)
+    pt_ptr = np.concatenate((sc.pt_ptr, [sc.pt_ptr[-1]])).astype(np.int32)
+    pts_plus = np.hstack((sc.pts_init, [[1.0], [2.0], [9.0]]))
+    cams, pts = hip.ba_solve(3, pt_ptr, sc.cam_idx, uvn, sc.cams_init, pts_plus, 5.0, 2)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    assert np.array_equal(pts[:, -1], [1.0, 2.0, 9.0])
+    assert rel(cams, ocams) < TOL and rel(pts[:, :-1], opts) < TOL
+    # a non-unit quaternion far from a rotation raises like convert_quaternion_to_rotation (ba:323)
+    bad = sc.cams_init.copy()
+    bad[1, 3:7] *= 1.05
+    with pytest.raises(ValueError):
+        hip.ba_solve(3, sc.pt_ptr, sc.cam_idx, uvn, bad, sc.pts_init, 5.0, 1)
+    # unsorted cameras inside a track are rejected
+    ci = sc.cam_idx.copy()
+    ci[[0, 1]] = ci[[1, 0]]
+    with pytest.raises(ValueError):
+        hip.ba_solve(3, sc.pt_ptr, ci, uvn, sc.cams_init, sc.pts_init, 5.0, 1)
+
+
+def test_ba_split_phases_equal_iterate(hip, sfm):
+    """linearize_reduce + solve_update (the multi-GPU split) == iterate on one rank."""
+    sc = sfm.scenes.make_scene(7, 500, 0.5, seed=4)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as a, hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as b:
+        for prob in (a, b):
+            prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS)
+            prob.set_state(sc.cams_init, sc.pts_init)
+        a.iterate(5.0, 2)
+        for _ in range(2):
+            b.linearize_reduce(5.0)
+            b.solve_update(5.0)
+        ca, pa = a.get_state()
+        cb, pb = b.get_state()
+    assert rel(ca, cb) < 1e-13 and rel(pa, pb) < 1e-13
+
+
+# ---- drop-in processors ---------------------------------------------------------------------------
+def test_processors_drop_in(hip, sfm, oracle, capsys):
+    g4 = load_golden("g4_tri.npz")
+    tp = sfm.processors.HipTriangulationProcessor()
+    whole = tp.triangulate([g4["lit_projs"][0], g4["lit_projs"][1]], [g4["lit_uv"][0], g4["lit_uv"][1]], 0.5, 300)
+    assert rel(whole, g4["lit_whole"]) < 1e-8            # linear DLT (host SVD) + device refinement
+    jx = tp.construct_jacobian_matrix(g4["lit_linear"], [g4["lit_projs"][0], g4["lit_projs"][1]], 2)
+    assert rel(jx, oracle.jac_pt(g4["lit_linear"][:, 0], [g4["lit_projs"][0], g4["lit_projs"][1]])) < 1e-12
+    # falsy arguments select the instance defaults (quirk Q4)
+    tp2 = sfm.processors.HipTriangulationProcessor(0.5, 10)
+    a = tp2.nonlinear_triangulate(g4["cv_init"], list(g4["cv_projs"]), list(g4["cv_uv"]), 0, 0)
+    assert rel(a, g4["cv_its10"]) < TOL
+    with pytest.raises(ValueError):
+        tp.triangulate([g4["lit_projs"][0]], [g4["lit_uv"][0], g4["lit_uv"][1]])
+
+    g5 = load_golden("g5_pnp.npz")
+    cp = sfm.processors.HipCamposeProcessor(None, 5, 25)
+    r, c = cp.nonlinear_estimate_cam_pose_pnp(g5["syn2_uv"], g5["syn2_X"], g5["syn_K"], g5["syn2_R0"], g5["syn2_C0"])
+    assert rel(r, g5["syn2_R"]) < TOL and rel(c, g5["syn2_C"]) < TOL and c.shape == (3, 1)
+    with pytest.raises(ValueError):
+        cp.nonlinear_estimate_cam_pose_pnp(g5["syn2_uv"][:, :5], g5["syn2_X"], g5["syn_K"], g5["syn2_R0"], g5["syn2_C0"])
+    jp = cp.construct_jacobian_matrix(g5["syn2_R0"], g5["syn2_C0"], g5["syn2_X"][:, 0:1])
+    assert rel(jp, oracle.jac_cam(g5["syn2_R0"], g5["syn2_C0"], g5["syn2_X"][:, 0])) < 1e-11
+
+    # BaProcessor.__execute_bundle_adjustment on duck-typed views / tracks (the reference's data contract)
+    g6 = load_golden("g6_ba_6x120v60.npz")
+
+    class KP:
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class View:
+        def __init__(self, rot, loc, k, kps):
+            self.rot, self.loc, self.k, self.key_pts = rot, loc, k, kps
+
+        def update_cam_pose(self, rot, loc):
+            self.rot, self.loc = rot, loc
+
+    class Track:
+        pass
+
+    class Holder:
+        pass
+
+    nv, npt = g6["cams_init"].shape[0], g6["pts_init"].shape[1]
+    views, tracks = [], []
+    for cidx in range(nv):
+        sel = np.flatnonzero(g6["cam_idx"] == cidx)
+        kps = [KP(-1.0, -1.0)] + [KP(float(g6["uv_pix"][0, o]), float(g6["uv_pix"][1, o])) for o in sel]
+        tr = Track()
+        tr.table = np.full((nv, len(kps)), -1, dtype=int)
+        tr.table[cidx, 1:] = g6["pt_idx"][sel]
+        tracks.append(tr)
+        views.append(View(sfm.geometry.quaternion_to_rotation(g6["cams_init"][cidx, 3:7]),
+                          g6["cams_init"][cidx, 0:3].reshape(3, 1).copy(), g6["K"].copy(), kps))
+    vp, kt, tpp = Holder(), Holder(), sfm.processors.HipTriangulationProcessor()
+    vp.view_list, kt.track_list = views, tracks
+    tpp.tri_pts = np.vstack((g6["pts_init"], np.ones((1, npt))))
+    bp = sfm.processors.HipBaProcessor(vp, kt, None, tpp, cp, iteration=3, damping_factor=5)
+    bp._BaProcessor__execute_bundle_adjustment()
+    out = capsys.readouterr().out
+    assert out.count("view loc distance changes") == nv
+    assert rel(tpp.tri_pts[0:3], g6["pts_it3"]) < TOL
+    assert np.all(tpp.tri_pts[3] == 1.0)
+    for cidx in range(nv):
+        assert rel(views[cidx].loc[:, 0], g6["cams_it3"][cidx, 0:3]) < TOL
+        assert rel(sfm.geometry.rotation_to_quaternion(views[cidx].rot)[:, 0], g6["cams_it3"][cidx, 3:7]) < TOL

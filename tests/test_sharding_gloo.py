@@ -1,0 +1,125 @@
+"""Multi-rank BA path on CPU: world_size-2 (and 3) `gloo` runs of structure-from-motion_amd.sharding
+with an oracle-backed engine standing in for the HIP engine.  This covers the host logic the GPU
+ranks use unchanged — shard bounds, CSR slicing, the one all-reduce of [S | rhs] per iteration, the
+redundant reduced solve, local back-substitution — and checks the result against a single-process run.
+"""
+import contextlib
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, ORACLE_DIR
+
+
+class OracleEngine:
+    """Same interface as sharding.HipShardEngine; partial system and update come from the oracle."""
+
+    def __init__(self, oracle, n_cams, ptr_l, cam_l, uv_l):
+        self.o = oracle
+        self.n_cams = n_cams
+        self.cam_idx = np.asarray(cam_l)
+        self.pt_idx = np.repeat(np.arange(ptr_l.shape[0] - 1), np.diff(ptr_l)).astype(np.int32)
+        self.uv = uv_l
+        self.buf = torch.zeros((7 * n_cams) ** 2 + 7 * n_cams, dtype=torch.float64)
+
+    def stream_context(self):
+        return contextlib.nullcontext()
+
+    def set_state(self, cams, pts_l):
+        self.cams = np.array(cams, dtype=np.float64).reshape(-1, 7)
+        self.pts = np.array(pts_l, dtype=np.float64)
+
+    def linearize_reduce(self, lam, quirks=3):
+        p = 7 * self.n_cams
+        self.t = self.o.ba_reduced_system(self.cams, self.pts, self.cam_idx, self.pt_idx, self.uv, lam, quirks)
+        s_partial = self.t["S"] - lam * np.eye(p)          # lambda I is added once, after the reduction
+        self.buf[:p * p] = torch.from_numpy(s_partial.reshape(-1))
+        self.buf[p * p:] = torch.from_numpy(self.t["rhs"])
+        return self.buf
+
+    def solve_update(self, lam, quirks=3):
+        p = 7 * self.n_cams
+        s = self.buf[:p * p].numpy().reshape(p, p) + lam * np.eye(p)
+        delta = (np.linalg.inv(s) @ self.buf[p * p:].numpy()).reshape(self.n_cams, 7)
+        self.cams = self.cams + delta
+        self.cams[:, 3:7] /= np.linalg.norm(self.cams[:, 3:7], axis=1)[:, None]
+        btd = np.zeros_like(self.t["ex"])
+        np.add.at(btd, self.pt_idx, np.einsum('mij,mi->mj', self.t["W"], delta[self.cam_idx]))
+        self.pts = self.pts + np.einsum('pij,pj->pi', self.t["D_inv"], self.t["ex"] - btd).T
+
+    def get_state(self):
+        return self.cams, self.pts
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, ORACLE_DIR)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sfm = importlib.import_module("structure-from-motion_amd")
+    oracle = importlib.import_module("sfm_oracle")
+    sc = sfm.scenes.make_scene(7, 400, 0.5, seed=17)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    bounds = sfm.sharding.shard_bounds(sc.pt_ptr, world)
+    ptr_l, cam_l, uv_l, pts_l, (p0, p1) = sfm.sharding.local_shard(sc.pt_ptr, sc.cam_idx, uvn, sc.pts_init, bounds, rank)
+    eng = OracleEngine(oracle, sc.n_cams, ptr_l, cam_l, uv_l)
+    eng.set_state(sc.cams_init, pts_l)
+    ba = sfm.sharding.ShardedBa(eng, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), world)
+    ba.iterate(5.0, 3)
+    cams, pts_loc = eng.get_state()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cams=cams, pts=pts_loc, p0=p0, p1=p1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ba_matches_single_process(sfm, oracle, tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sc = sfm.scenes.make_scene(7, 400, 0.5, seed=17)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    pts = np.empty_like(opts)
+    covered = 0
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.max(np.abs(g["cams"] - ocams)) / np.max(np.abs(ocams)) < 1e-12      # identical solve on every rank
+        pts[:, int(g["p0"]):int(g["p1"])] = g["pts"]
+        covered += int(g["p1"]) - int(g["p0"])
+    assert covered == sc.n_pts
+    assert np.max(np.abs(pts - opts)) / np.max(np.abs(opts)) < 1e-12
+
+
+def test_shard_bounds_properties(sfm):
+    sc = sfm.scenes.make_scene(10, 1000, 0.4, seed=3)
+    for world in (1, 2, 4, 8):
+        b = sfm.sharding.shard_bounds(sc.pt_ptr, world)
+        assert b[0] == 0 and b[-1] == sc.n_pts and np.all(np.diff(b) >= 0) and b.shape[0] == world + 1
+        k = np.diff(sc.pt_ptr).astype(float)
+        w = k * (k + 1) / 2
+        loads = np.array([w[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert loads.max() / loads.mean() < 1.1                     # balanced by camera-pair count
+        # shards tile the observation list exactly
+        tot = 0
+        for r in range(world):
+            ptr, cam, uv, pts, (p0, p1) = sfm.sharding.local_shard(sc.pt_ptr, sc.cam_idx, np.zeros((2, sc.n_obs)), sc.pts_init, b, r)
+            assert ptr[0] == 0 and ptr[-1] == cam.shape[0] and pts.shape[1] == p1 - p0
+            tot += cam.shape[0]
+        assert tot == sc.n_obs
+    # more ranks than points: empty shards are legal
+    b = sfm.sharding.shard_bounds(np.array([0, 2, 4]), 4)
+    assert b[0] == 0 and b[-1] == 2 and np.all(np.diff(b) >= 0)
