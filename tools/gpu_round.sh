@@ -1,0 +1,31 @@
+#!/bin/bash
+# One gpurun call = GPU tests + smoke + bench + rocprofv3 kernel stats (each call pays ~10 min of
+# box acquisition, so everything rides in one).  Usage (from the repo root on the GPU box):
+#   bash tools/gpu_round.sh [tag]
+# Stops at the first step that is killed/timed out (rc >= 124); ordinary test failures do not stop it.
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+step() {   # step <seconds> <logfile> <cmd...>
+  local secs=$1 log=$2; shift 2
+  echo "== $* (limit ${secs}s)" | tee -a "$out/steps.log"
+  timeout -k 10 "$secs" "$@" > "$log" 2>&1
+  local rc=$?
+  echo "   rc=$rc" | tee -a "$out/steps.log"
+  if [ $rc -ge 124 ]; then echo "step killed; stopping" | tee -a "$out/steps.log"; exit $rc; fi
+  return 0
+}
+step 600 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 300
+tail -5 "$out/pytest_gpu.log"
+step 120 "$out/smoke.log" python __graft_entry__.py smoke
+tail -2 "$out/smoke.log"
+step 240 "$out/bench.log" python bench.py --steps 20 --warmup 3
+tail -1 "$out/bench.log"
+step 240 "$out/bench_pairs.log" python bench.py --steps 5 --warmup 1 --schur pairs --no-cpu-baseline
+tail -1 "$out/bench_pairs.log"
+step 300 "$out/rocprof.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
+find "$out/prof" -name "*kernel_stats*" | head -3
+f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -25 "$f"
+exit 0
