@@ -27,9 +27,10 @@ struct BaDev {
   double* pz = nullptr;
   // per-iteration scratch
   CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
-  double* Z = nullptr;      // [M][21]  Z_o = (Jp^T Jx) L_p^-T
+  double* Z = nullptr;      // [21][M] (SoA)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j
   double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
   double* delta = nullptr;  // [ld] camera update
+  double* ldiag = nullptr;  // [ceil(P/32)][32][32] Cholesky factors of the diagonal blocks
   int* status = nullptr;    // [2] first failure code, camera index
 };
 
@@ -52,14 +53,17 @@ struct sfm_ba_problem {
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)
-  void* schur_ws = nullptr;
+  void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
+  int* schur_slot = nullptr;     // [N][schur_vpad] observation index of (point, camera) or -1
+  int schur_vpad = 0;
+  bool schur_mfma_ok = false;
   int schur_chunks = 0;
   int schur_pts_per_chunk = 0;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 
 namespace sfm {
-int ba_schur_plan(sfm_ba_problem* p);
+int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);

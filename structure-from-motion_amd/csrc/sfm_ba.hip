@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
         obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
       }
-      double* zo = d.Z + (size_t)o * 21;
+      double* zo = d.Z + o;                     // SoA: element e of observation o at Z[e * M + o]
+      const size_t zs = (size_t)d.M;
       double acc[35];
       int k = 0;
 #pragma unroll
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         const double z0 = w0 * li[0];
         const double z1 = w0 * li[1] + w1 * li[2];
         const double z2 = w0 * li[3] + w1 * li[4] + w2 * li[5];
-        zo[3 * i + 0] = z0; zo[3 * i + 1] = z1; zo[3 * i + 2] = z2;
+        zo[(3 * i + 0) * zs] = z0; zo[(3 * i + 1) * zs] = z1; zo[(3 * i + 2) * zs] = z2;
 #pragma unroll
         for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
         acc[28 + i] = Jp[i] * r[0] + Jp[7 + i] * r[1] - (z0 * y0 + z1 * y1 + z2 * y2);
@@ -255,137 +256,224 @@ __global__ void ba_residual_jacobian_kernel(BaDev d, int cur, int quirks, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reduced solve.  S (+ lambda I) = L L^T by a blocked left-looking Cholesky, one launch per 32-wide
-// panel; workgroup b owns the 32-row block b of the panel (block 0 = the diagonal block) and the last
-// workgroup owns the rhs row, which rides along as an extra matrix row so the forward solve L y = rhs
-// needs no pass of its own.  Every workgroup recomputes and factors the 32x32 diagonal block
-// (cheap) instead of waiting for another workgroup.  L overwrites the lower triangle of S.
+// Reduced solve.  S + lambda I = L L^T by a blocked right-looking Cholesky on 32x32 blocks, one launch
+// per block column j.  Workgroup (r, c), j <= c <= r, first applies the previous panel's update
+// A[r][c] -= L[r][j-1] L[c][j-1]^T (K = 32, all 256 threads).  Blocks right of column j store the
+// result and leave.  Blocks in column j then need the factor of the diagonal block: every one of them
+// recomputes D = A[j][j] - L[j][j-1] L[j][j-1]^T + lambda I locally (nobody writes S(j,j) in this
+// launch, so there is no race) and hands [D; T] to ONE wave that runs a register-resident elimination
+// with lanes 0..31 = rows of D and lanes 32..63 = rows of T: the column steps that factor D
+// (l_jj = sqrt(d_jj), rank-1 trailing update, operands broadcast with v_readlane) perform the
+// triangular solve X L_d^T = T on the other 32 lanes in the same instruction stream.  The rhs vector
+// rides along as block row `nbk` (one valid row), so L y = rhs needs no pass of its own.
+// L overwrites the strictly-lower blocks of S in place; diagonal factors go to d.ldiag.
 // ---------------------------------------------------------------------------------------------
 constexpr int NB = 32;
 
-__global__ __launch_bounds__(256) void ba_chol_panel_kernel(double* __restrict__ S, double* __restrict__ rhs, int ld,
-                                                            int P, int c0, double lambda) {
-  __shared__ double Ld[NB][NB + 1];   // diagonal block, then its Cholesky factor
-  __shared__ double T[NB][NB + 1];    // this workgroup's row block
-  __shared__ double Lc[NB][NB + 1];   // K-chunk of the panel's block row  L[c0.., kc..]
-  __shared__ double Lr[NB][NB + 1];   // K-chunk of this workgroup's rows   L[r0.., kc..]
-  const int nb = min(NB, P - c0);
-  const int nrb = (P - c0 + NB - 1) / NB;
-  const int rb = blockIdx.x;            // 0..nrb-1 row blocks, nrb = rhs row
-  const bool is_rhs = rb == nrb;
-  const int r0 = c0 + rb * NB;
-  const int nr = is_rhs ? 1 : min(NB, P - r0);
-  const int tid = threadIdx.x;
-  const int ti = tid / NB, tj = tid % NB;     // 8 x 32 thread grid; each thread owns rows ti + 8e
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
 
-  double accD[4] = {0, 0, 0, 0}, accT[4] = {0, 0, 0, 0};
-  for (int kc = 0; kc < c0; kc += NB) {
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      Lc[i][tj] = (i < nb) ? S[(size_t)(c0 + i) * ld + kc + tj] : 0.0;
-      double v = 0.0;
-      if (i < nr) v = is_rhs ? rhs[kc + tj] : S[(size_t)(r0 + i) * ld + kc + tj];
-      Lr[i][tj] = v;
-    }
-    __syncthreads();
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      double sd = 0, st = 0;
-#pragma unroll 8
-      for (int k = 0; k < NB; ++k) {
-        const double cj = Lc[tj][k];
-        sd += Lc[i][k] * cj;
-        st += Lr[i][k] * cj;
-      }
-      accD[e] += sd;
-      accT[e] += st;
-    }
-    __syncthreads();
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (the library 1.0/sqrt(d) is
+// ~50 dependent instructions and sits on the critical path of every column step).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  r = r * (1.5 - h * r * r);
+  r = r * (1.5 - h * r * r);
+  return r;
+}
+
+// One wave: a[] = this lane's row (lanes 0..31: rows of the SPD block D, lower part valid; lanes
+// 32..63: rows of T).  On return lanes 0..31 hold the rows of L_d (lower) and lanes 32..63 the rows of
+// X = T L_d^-T.  Column j of L_d is published through a 32-double LDS buffer and read back with
+// wave-uniform addresses (LDS broadcast): one ds_read + one FMA per trailing entry, no SGPR hazards.
+// Single wave => its LDS operations execute in order; no barrier is needed.
+__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], double (*colbuf)[NB], int lane) {
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double inv = rsqrt_nr(lane_bcast(a[j], j));
+    a[j] *= inv;
+    double* cb = colbuf[j & 1];
+    if (lane < NB) cb[lane] = a[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = j + 1; k < NB; ++k) a[k] -= a[j] * cb[k];
   }
+}
+
+__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
+  __shared__ double La[NB][NB + 1];   // L[r][j-1]
+  __shared__ double Lb[NB][NB + 1];   // L[c][j-1]
+  __shared__ double Lj[NB][NB + 1];   // L[j][j-1] (column-j blocks with r != j)
+  __shared__ double Tm[NB][NB + 1];
+  __shared__ double Dm[NB][NB + 1];
+  __shared__ double colbuf[2][NB];
+  const int P = d.P, ld = d.ld;
+  const int nbk = (P + NB - 1) / NB;
+  const int c = j + blockIdx.x, r = j + blockIdx.y;
+  if (r < c) return;
+  const bool is_rhs = r == nbk;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)ld * ld;
+  const int r0 = r * NB, c0 = c * NB, j0 = j * NB, k0 = (j - 1) * NB;
+  const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
+  const bool col_j = c == j;
+  const bool need_d = col_j && r != j;
+  const bool col_ok = c0 + tj < P;
+
+  // block rows past P (last block) and the 31 unused rows of the rhs block read as zero
+  auto row_ptr = [&](int blk_r0, int i, bool rhs_row) -> const double* {
+    if (rhs_row) return i == 0 ? rhs : nullptr;
+    return (blk_r0 + i < P) ? S + (size_t)(blk_r0 + i) * ld : nullptr;
+  };
+
+  // every global load of the step is issued before the first wait
+  double aT[4], aD[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0}, lj[4] = {0, 0, 0, 0};
+#pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int i = ti + 8 * e;
-    double dv = 0.0, tv = 0.0;
-    if (i < nb && tj < nb && tj <= i) dv = S[(size_t)(c0 + i) * ld + c0 + tj] + (i == tj ? lambda : 0.0) - accD[e];
-    if (i < nr && tj < nb) tv = (is_rhs ? rhs[c0 + tj] : S[(size_t)(r0 + i) * ld + c0 + tj]) - accT[e];
-    Ld[i][tj] = dv;
-    T[i][tj] = tv;
+    const double* pr = row_ptr(r0, i, is_rhs);
+    const double* pc = row_ptr(c0, i, false);
+    const double* pj = row_ptr(j0, i, false);
+    aT[e] = (pr && col_ok) ? pr[c0 + tj] : 0.0;
+    if (need_d) aD[e] = (pj && col_ok) ? pj[j0 + tj] : 0.0;
+    if (j > 0) {
+      la[e] = pr ? pr[k0 + tj] : 0.0;
+      lb[e] = pc ? pc[k0 + tj] : 0.0;
+      if (need_d) lj[e] = pj ? pj[k0 + tj] : 0.0;
+    }
   }
+  if (j > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      La[i][tj] = la[e];
+      Lb[i][tj] = lb[e];
+      if (need_d) Lj[i][tj] = lj[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      double st = 0, sd = 0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        st += La[i][k] * Lb[tj][k];
+        if (need_d) sd += Lj[i][k] * Lj[tj][k];
+      }
+      aT[e] -= st;
+      aD[e] -= sd;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = ti + 8 * e;
+    const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
+    double t = (row_ok && col_ok) ? aT[e] : 0.0;
+    if (!col_j) {
+      if (row_ok && col_ok) (is_rhs ? rhs : S + (size_t)(r0 + i) * ld)[c0 + tj] = t;
+      continue;
+    }
+    if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
+      if (i == tj) t = col_ok ? t + lambda : 1.0;
+      Dm[i][tj] = t;
+      Tm[i][tj] = 0.0;
+    } else {
+      Tm[i][tj] = t;
+      double dv = (j0 + i < P && col_ok) ? aD[e] : 0.0;
+      if (i == tj) dv = col_ok ? dv + lambda : 1.0;
+      Dm[i][tj] = dv;
+    }
+  }
+  if (!col_j) return;
   __syncthreads();
-  // factor the diagonal block in LDS (right-looking, nb steps)
-  for (int j = 0; j < nb; ++j) {
-    const double djj = sqrt(Ld[j][j]);
-    __syncthreads();
-    if (tid < nb && tid >= j) Ld[tid][j] = (tid == j) ? djj : Ld[tid][j] / djj;
-    __syncthreads();
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      if (i > j && tj > j && tj <= i && i < nb) Ld[i][tj] -= Ld[i][j] * Ld[tj][j];
+  if (tid >= 64) return;
+  const int lane = tid;
+  double a[NB];
+  const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
+  const int row = lane & (NB - 1);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) a[k] = src[row][k];
+  chol_trsm_rows(a, colbuf, lane);
+  if (r == j) {
+    if (lane < NB) {
+      double* out = d.ldiag + ((size_t)j * NB + row) * NB;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) out[k] = (k <= row) ? a[k] : 0.0;
     }
-    __syncthreads();
-  }
-  if (rb == 0) {
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      if (i < nb && tj <= i) S[(size_t)(c0 + i) * ld + c0 + tj] = Ld[i][tj];
-    }
-  } else {
-    // X Ld^T = T : one thread per row, forward substitution over the nb columns
-    if (tid < nr) {
-      for (int j = 0; j < nb; ++j) {
-        double s = T[tid][j];
-        for (int k = 0; k < j; ++k) s -= T[tid][k] * Ld[j][k];
-        T[tid][j] = s / Ld[j][j];
+  } else if (lane >= NB) {
+    if (is_rhs) {
+      if (row == 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (c0 + k < P) rhs[c0 + k] = a[k];
       }
-    }
-    __syncthreads();
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      if (i < nr && tj < nb) {
-        if (is_rhs) rhs[c0 + tj] = T[i][tj];
-        else S[(size_t)(r0 + i) * ld + c0 + tj] = T[i][tj];
-      }
+    } else if (r0 + row < P) {
+      double* out = S + (size_t)(r0 + row) * ld + c0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) out[k] = a[k];
     }
   }
 }
 
-// L^T dp = y (y sits in rhs after the panels), then the camera update of ba:383-392 and the
-// preparation of the next iteration's cameras.  Single workgroup.
+// L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one workgroup:
+// per block one wave solves the 32x32 upper-triangular system with lane i holding column i of L_d
+// (static register indexing; the next block's column is prefetched while all threads fold x_b into
+// the y of the blocks above, 32 independent coalesced loads per thread).  Then the camera update of
+// ba:383-392 and the preparation of the next iteration.
 __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
-  __shared__ double Ld[NB][NB + 1];
   __shared__ double xb[NB];
   const int P = d.P, ld = d.ld;
   const double* S = d.red;
   double* y = d.red + (size_t)ld * ld;
   const int tid = threadIdx.x;
-  const int nblk = (P + NB - 1) / NB;
-  for (int b = nblk - 1; b >= 0; --b) {
+  const int lane = tid & (NB - 1);
+  const int nbk = (P + NB - 1) / NB;
+  double col[NB], rdi = 1.0;
+  if (tid < 64) {
+    const double* Ld = d.ldiag + (size_t)(nbk - 1) * NB * NB;
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];      // column `lane` of L_d (zero above the diagonal)
+  }
+  for (int b = nbk - 1; b >= 0; --b) {
     const int c0 = b * NB;
-    const int nb = min(NB, P - c0);
-    for (int t = tid; t < NB * NB; t += blockDim.x) {
-      const int i = t / NB, j = t % NB;
-      Ld[i][j] = (i < nb && j <= i) ? S[(size_t)(c0 + i) * ld + c0 + j] : 0.0;
-    }
-    __syncthreads();
     if (tid < 64) {
-      // one wave: lane i holds y_i of the block; columns are eliminated from the last to the first
-      double yi = (tid < nb) ? y[c0 + tid] : 0.0;
-      for (int j = nb - 1; j >= 0; --j) {
-        const double xj = __shfl(yi, j, 64) / Ld[j][j];
-        if (tid == j) yi = xj;
-        else if (tid < j) yi -= Ld[j][tid] * xj;
+      double diag = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) diag = (lane == jj) ? col[jj] : diag;    // L_d[lane][lane]
+      rdi = 1.0 / diag;
+      double yi = (c0 + lane < P) ? y[c0 + lane] : 0.0;
+      double xi = 0.0;
+#pragma unroll
+      for (int jj = NB - 1; jj >= 0; --jj) {
+        const double xj = lane_bcast(yi * rdi, jj);
+        if (lane == jj) xi = xj;
+        yi -= col[jj] * xj;              // lanes >= jj: col[jj] multiplies a value no longer used
       }
-      if (tid < nb) { xb[tid] = yi; d.delta[c0 + tid] = yi; }
+      if (tid < NB) {
+        xb[lane] = (c0 + lane < P) ? xi : 0.0;
+        if (c0 + lane < P) d.delta[c0 + lane] = xi;
+      }
     }
     __syncthreads();
+    if (tid < 64 && b > 0) {             // prefetch the next diagonal factor; lands during the update below
+      const double* Ld = d.ldiag + (size_t)(b - 1) * NB * NB;
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];
+    }
     for (int i = tid; i < c0; i += blockDim.x) {
+      double v[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) v[k] = S[(size_t)(c0 + k) * ld + i];   // rows >= P are zero (memset, never written)
       double s = 0;
-      for (int k = 0; k < nb; ++k) s += S[(size_t)(c0 + k) * ld + i] * xb[k];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) s += v[k] * xb[k];
       y[i] -= s;
     }
     __syncthreads();
   }
-  __threadfence_block();
-  __syncthreads();
   for (int c = tid; c < d.V; c += blockDim.x) {
     double cam[7];
     for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383
@@ -494,12 +582,11 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = ctx().stream;
   const BaDev& d = p->dev;
-  double* S = d.red;
-  double* rhs = d.red + (size_t)d.ld * d.ld;
   tick(p, SFM_K_SOLVE, true, s);
-  for (int c0 = 0; c0 < d.P; c0 += NB) {
-    const int nrb = (d.P - c0 + NB - 1) / NB;
-    ba_chol_panel_kernel<<<nrb + 1, 256, 0, s>>>(S, rhs, d.ld, d.P, c0, lambda);
+  const int nbk = (d.P + NB - 1) / NB;
+  for (int j = 0; j < nbk; ++j) {
+    dim3 grid(nbk - j, nbk - j + 1);            // (block column c - j, block row r - j); row nbk = the rhs
+    ba_chol_step_kernel<<<grid, 256, 0, s>>>(d, j, lambda);
   }
   ba_back_solve_kernel<<<1, 256, 0, s>>>(d, p->cur);
   tick(p, SFM_K_SOLVE, false, s);
@@ -586,6 +673,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   BA_ALLOC(d.Z, (size_t)M * 21);
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
+  BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
   BA_ALLOC(d.status, 2);
 #undef BA_ALLOC
   d.red = p->own_red;
@@ -601,7 +689,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipStreamSynchronize(s) != hipSuccess) return fail(SFM_E_HIP);
-  SFM_TRY(ba_schur_plan(p));
+  { const int st_plan = ba_schur_plan(p, pt_ptr, cam_idx); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
   return SFM_OK;
 }
@@ -612,7 +700,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, p->own_red, d.delta, d.status, p->schur_ws};
+                  d.Z, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_slot};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

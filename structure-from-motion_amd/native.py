@@ -49,6 +49,14 @@ def load():
         raise SfmHipError(
             "libsfm_hip.so not found at %s — build it with `make -C %s` (there is no CPU fallback)"
             % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    # When PyTorch is in the process it must load its ROCm runtime FIRST: torch bundles its own
+    # libamdhip64/libhsa-runtime64, and two HSA runtimes in one process leave the second one without
+    # devices ("no ROCm-capable device is detected").  With torch imported first, libsfm_hip.so binds to
+    # the already-loaded runtime and both share streams and device memory.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.sfm_last_error.restype = ctypes.c_char_p
     lib.sfm_set_stream.argtypes = [ctypes.c_void_p]

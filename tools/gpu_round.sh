@@ -27,5 +27,9 @@ tail -1 "$out/bench_pairs.log"
 step 300 "$out/rocprof.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
 find "$out/prof" -name "*kernel_stats*" | head -3
 f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -25 "$f"
+[ -n "$f" ] && head -14 "$f"
+# HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), no other trace domains
+step 300 "$out/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+step 300 "$out/pmc_write.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+python3 tools/parse_pmc.py "$out/pmc_fetch" "$out/pmc_write" "$out/traffic.json"
 exit 0
