@@ -156,8 +156,14 @@ def main():
     roofline["traffic"] = None
     tfile = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tfile):
-        try:
-            roofline["traffic"] = json.load(open(tfile)).get("ba_" + dominant)
+        try:      # a kernel class may be several kernels (schur = schur_mfma + schur_reduce, solve = chol_step x11 + back_solve)
+            tj = json.load(open(tfile))
+            prefix = {"solve": ("ba_chol_step", "ba_back_solve")}.get(dominant, ("ba_" + dominant,))
+            per = {k: v for k, v in tj.items() if k.startswith(prefix) and isinstance(v, (int, float))}
+            if per:
+                mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32}
+                roofline["traffic"] = sum(v * mult.get(k, 1) for k, v in per.items())
+                roofline["traffic_unit"] = "HBM bytes per iteration of this kernel class (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
         except Exception:
             pass
 
@@ -181,6 +187,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1): the NumPy block-sparse oracle, 3 iterations of the same scene
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        engine.close()
         sys.path.insert(0, os.path.join(REPO, "oracle"))
         oracle = importlib.import_module("sfm_oracle")
         n_cpu_iters = 3
@@ -202,8 +209,15 @@ def main():
             "cams": float(np.max(np.abs(cams3 - ocams)) / np.max(np.abs(ocams))),
             "pts": float(np.max(np.abs(pts3 - opts)) / np.max(np.abs(opts)))}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # PCIe-inclusive rate of the host-buffer entry point (sfm_ba_solve: create + upload + 3 iterations +
+        # download), for DESIGN.md; never used as `value`
+        native.set_stream(0)
+        t0 = time.perf_counter()
+        native.ba_solve(scene.n_cams, scene.pt_ptr, scene.cam_idx, uvn, scene.cams_init, scene.pts_init, LAMBDA, 3)
+        out["host_buffer_path"] = {"seconds_for_3_iterations_incl_setup_and_pcie": time.perf_counter() - t0}
 
-    engine.close()
+    if world > 1 or args.no_cpu_baseline:
+        engine.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

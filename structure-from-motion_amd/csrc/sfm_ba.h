@@ -27,7 +27,9 @@ struct BaDev {
   double* pz = nullptr;
   // per-iteration scratch
   CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
-  double* Z = nullptr;      // [21][M] (SoA)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j
+  double* Z = nullptr;      // [21][M] (SoA)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j; pair-kernel path only (lazy)
+  double* lin_ws = nullptr; // [linearize workgroups][V][35] per-workgroup camera accumulators (U lower 28 | rhs 7)
+  double* lip = nullptr;    // [N][6] L_p^-1 (lower, packed) of V_p = sum Jx^T Jx + lambda I
   double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
   double* delta = nullptr;  // [ld] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] Cholesky factors of the diagonal blocks
@@ -50,6 +52,7 @@ struct sfm_ba_problem {
   bool prep_valid = false;
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
+  int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight (the Schur producers re-derive it)
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)
@@ -65,6 +68,7 @@ struct sfm_ba_problem {
 namespace sfm {
 int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
+bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);

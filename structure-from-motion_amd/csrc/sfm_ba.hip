@@ -59,7 +59,7 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // ba_linearize: G lanes per point (G = power of two <= 64 chosen from the mean track length).
 // LDS: [V][19] prepared cameras + [V][35] camera-side accumulators when they fit (CAMS_IN_LDS).
 // ---------------------------------------------------------------------------------------------
-template <int G, bool CAMS_IN_LDS>
+template <int G, bool CAMS_IN_LDS, bool WRITE_Z>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   extern __shared__ double lds[];
   double* lds_prep = lds;                    // V * 19
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     const double y0 = li[0] * g3[0];
     const double y1 = li[1] * g3[0] + li[2] * g3[1];
     const double y2 = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
+    if (!WRITE_Z && lane_g == 0 && p < d.N) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d.lip[(size_t)p * 6 + k] = li[k];      // 48 B/point for the Schur producers
+    }
     const bool single = (end - beg) <= G;
     for (int o = beg + lane_g; o < end; o += G) {
       if (!single) {
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
         obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
       }
-      double* zo = d.Z + o;                     // SoA: element e of observation o at Z[e * M + o]
+      double* zo = WRITE_Z ? d.Z + o : nullptr;   // SoA: element e of observation o at Z[e * M + o]
       const size_t zs = (size_t)d.M;
       double acc[35];
       int k = 0;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         const double z0 = w0 * li[0];
         const double z1 = w0 * li[1] + w1 * li[2];
         const double z2 = w0 * li[3] + w1 * li[4] + w2 * li[5];
-        zo[(3 * i + 0) * zs] = z0; zo[(3 * i + 1) * zs] = z1; zo[(3 * i + 2) * zs] = z2;
+        if (WRITE_Z) { zo[(3 * i + 0) * zs] = z0; zo[(3 * i + 1) * zs] = z1; zo[(3 * i + 2) * zs] = z2; }
 #pragma unroll
         for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
         acc[28 + i] = Jp[i] * r[0] + Jp[7 + i] * r[1] - (z0 * y0 + z1 * y1 + z2 * y2);
@@ -155,20 +159,35 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     }
   }
   if (CAMS_IN_LDS) {
+    // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_cam_reduce_kernel adds
+    // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
+    // addresses: ~18 G atomics/s on MI355X, 50 us at C3.)
     __syncthreads();
-    for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) {
-      const double val = lds_acc[t];
-      if (val == 0.0) continue;
-      const int c = t / 35, e = t % 35;
-      if (e >= 28) {
-        atomicAdd(&rhs[7 * c + (e - 28)], val);
-      } else {
-        int i = 0, base = 0;                   // e = i(i+1)/2 + j
-        while (base + i + 1 <= e) { base += i + 1; ++i; }
-        const int j = e - base;
-        atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + j], val);
-      }
-    }
+    double* row = d.lin_ws + (size_t)blockIdx.x * d.V * 35;
+    for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) row[t] = lds_acc[t];
+  }
+}
+
+// Sum the per-workgroup camera accumulators of ba_linearize into the diagonal blocks of S (lower
+// part) and rhs.  grid = (ceil(35 V / 256), 48): slice g adds its share of the workspace rows and
+// finishes with one f64 atomic per element (48-way instead of 768-way contention).
+__global__ __launch_bounds__(256) void ba_cam_reduce_kernel(BaDev d, int nrows) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.V * 35) return;
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
+  double s = 0;
+  for (int r = r0; r < r1; ++r) s += d.lin_ws[(size_t)r * d.V * 35 + t];
+  if (s == 0.0) return;
+  const int c = t / 35, e = t % 35;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)d.ld * d.ld;
+  if (e >= 28) {
+    atomicAdd(&rhs[7 * c + (e - 28)], s);
+  } else {
+    int i = 0, base = 0;                   // e = i(i+1)/2 + j
+    while (base + i + 1 <= e) { base += i + 1; ++i; }
+    atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + (e - base)], s);
   }
 }
 
@@ -292,15 +311,21 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // wave-uniform addresses (LDS broadcast): one ds_read + one FMA per trailing entry, no SGPR hazards.
 // Single wave => its LDS operations execute in order; no barrier is needed.
 __device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], double (*colbuf)[NB], int lane) {
+  // Software-pipelined over columns: the two trailing columns the NEXT pivots depend on are updated
+  // through register broadcasts (no LDS round trip on the critical path, which is then
+  // rsqrt -> scale -> broadcast -> fma); the remaining trailing columns stream through the LDS buffer.
+  constexpr int FAST = 2;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const double inv = rsqrt_nr(lane_bcast(a[j], j));
     a[j] *= inv;
+#pragma unroll
+    for (int k = j + 1; k < NB && k <= j + FAST; ++k) a[k] -= a[j] * lane_bcast(a[j], k);
     double* cb = colbuf[j & 1];
     if (lane < NB) cb[lane] = a[j];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = j + 1; k < NB; ++k) a[k] -= a[j] * cb[k];
+    for (int k = j + 1 + FAST; k < NB; ++k) a[k] -= a[j] * cb[k];
   }
 }
 
@@ -355,18 +380,22 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       if (need_d) Lj[i][tj] = lj[e];
     }
     __syncthreads();
+    // k outermost: the column operand Lb[tj][k] is read once per k and reused by the thread's 4 rows; the
+    // row operands La[i][k] are wave-broadcast reads (all 32 lanes of a row share the address)
+    double st[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      double st = 0, sd = 0;
+    for (int k = 0; k < NB; ++k) {
+      const double b = Lb[tj][k];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        st += La[i][k] * Lb[tj][k];
-        if (need_d) sd += Lj[i][k] * Lj[tj][k];
+      for (int e = 0; e < 4; ++e) st[e] += La[ti + 8 * e][k] * b;
+      if (need_d) {
+        const double bj = Lj[tj][k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sd[e] += Lj[ti + 8 * e][k] * bj;
       }
-      aT[e] -= st;
-      aD[e] -= sd;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { aT[e] -= st[e]; aD[e] -= sd[e]; }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -499,6 +528,8 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ S, int ld, int P
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+constexpr int kLinGridPerCu = 3;   // ba_linearize workgroups per CU (168 VGPRs -> 3 waves/SIMD)
+
 static int pick_group(const sfm_ba_problem* p) {
   // lanes per point: smallest power of two >= mean track length (clamped to [4, 64]); longer tracks loop
   double mean = p->dev.N > 0 ? (double)p->dev.M / p->dev.N : 1.0;
@@ -507,15 +538,15 @@ static int pick_group(const sfm_ba_problem* p) {
   return g;
 }
 
-template <bool LDS>
+template <bool LDS, bool WZ>
 static void launch_linearize(const sfm_ba_problem* p, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
   const BaDev& d = p->dev;
   switch (g) {
-    case 4: ba_linearize_kernel<4, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 8: ba_linearize_kernel<8, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 16: ba_linearize_kernel<16, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 32: ba_linearize_kernel<32, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    default: ba_linearize_kernel<64, LDS><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 4: ba_linearize_kernel<4, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 8: ba_linearize_kernel<8, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 16: ba_linearize_kernel<16, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 32: ba_linearize_kernel<32, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    default: ba_linearize_kernel<64, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
   }
 }
 
@@ -565,12 +596,26 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
   const int g = pick_group(p);
   const int gpb = 256 / g;
-  int grid = std::min((d.N + gpb - 1) / gpb, 2 * ctx().num_cus);
+  int grid = std::min((d.N + gpb - 1) / gpb, kLinGridPerCu * ctx().num_cus);
   if (grid < 1) grid = 1;
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);
   tick(p, SFM_K_LINEARIZE, true, s);
-  if (lds <= 64 * 1024) launch_linearize<true>(p, g, grid, lds, s, lambda, quirks);
-  else launch_linearize<false>(p, g, grid, 0, s, lambda, quirks);
+  p->quirks = quirks;
+  const bool write_z = !ba_schur_uses_mfma(p);
+  if (write_z && d.Z == nullptr && d.M > 0) {      // pair-kernel path: Z = (Jp^T Jx) L^-T is materialised (168 B/obs)
+    SFM_HIP(hipMalloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
+  }
+  if (lds <= 64 * 1024) {
+    if (write_z) launch_linearize<true, true>(p, g, grid, lds, s, lambda, quirks);
+    else launch_linearize<true, false>(p, g, grid, lds, s, lambda, quirks);
+  } else {
+    if (write_z) launch_linearize<false, true>(p, g, grid, 0, s, lambda, quirks);
+    else launch_linearize<false, false>(p, g, grid, 0, s, lambda, quirks);
+  }
+  if (lds <= 64 * 1024) {
+    dim3 rgrid((d.V * 35 + 255) / 256, 48);
+    ba_cam_reduce_kernel<<<rgrid, 256, 0, s>>>(d, grid);
+  }
   tick(p, SFM_K_LINEARIZE, false, s);
   SFM_HIP(hipGetLastError());
   tick(p, SFM_K_SCHUR, true, s);
@@ -670,7 +715,8 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   BA_ALLOC(d.cams, (size_t)V * 7);
   BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
   BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
-  BA_ALLOC(d.Z, (size_t)M * 21);
+  BA_ALLOC(d.lip, (size_t)N * 6);
+  BA_ALLOC(d.lin_ws, (sizeof(double) * V * (19 + 35) <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
@@ -700,7 +746,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_slot};
+                  d.Z, d.lip, d.lin_ws, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_slot};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

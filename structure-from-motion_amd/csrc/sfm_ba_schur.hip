@@ -6,9 +6,10 @@
 //                           (a >= b) x 49 entries as lane tasks, f64 atomics into S.  Work is
 //                           proportional to sum_p k_p (k_p+1)/2 (sparse-optimal); bound by the f64
 //                           atomic rate.  Used for small or sparse scenes.
-//   ba_schur_mfma_kernel    dense  v_mfma_f64_16x16x4_f64  SYRK over zero-filled LDS tiles of Z^T,
-//                           output-stationary 64x64 tiles x split-K chunks of points; no atomics on
-//                           the inner loop.  Used when visibility is high enough that dense wins.
+//   ba_schur_mfma_kernel    dense  v_mfma_f64_16x16x4_f64  SYRK over LDS images of Z^T that producer waves
+//                           re-derive from the 20 B/observation inputs (Z never touches HBM);
+//                           output-stationary 128x128 tiles x split-K chunks of points; no atomics.
+//                           Used when visibility is high enough that dense wins.
 #include <algorithm>
 #include <vector>
 
@@ -47,17 +48,22 @@ __global__ __launch_bounds__(64) void ba_schur_pairs_kernel(BaDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense MFMA product.  Cameras are grouped into row blocks of CB = 18 (126 rows, padded to RB = 128
-// = 8 MFMA row strips), so block boundaries never cut a camera.  Grid = (lower-triangular 128x128
-// output tiles) x (point chunks).  A workgroup (8 waves) walks its chunk in slabs of SP = 8 points
-// (24 k-columns): thread (which, point, camera slot) looks the observation up in the slot table
-// (slot_obs[p][cam] = observation index or -1, built at create time) and writes that camera's
-// 7x3 block of Z -- or zeros -- straight to its fixed place in the [k][row] LDS image: no zero-fill
-// pass, no filtering, coalesced SoA reads of Z.  Each wave owns a 64x32 part (4x2 MFMA tiles):
-// 6 ds_read_b64 + 8 v_mfma_f64_16x16x4_f64 per k-step.  A operand: lane l holds A[row = l&15][k = l>>4];
-// B operand: B[k = l>>4][col = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.  Waves of a diagonal
-// tile that lie entirely above the diagonal skip their MFMAs.  Partial tiles go to per-(chunk, tile)
-// slabs (plain stores), summed into S by ba_schur_reduce_kernel.
+// Dense MFMA product, fused with the re-linearisation (no Z in HBM).
+//
+// Cameras are grouped into row blocks of CB = 18 (126 rows, padded to RB = 128 = 8 MFMA row strips),
+// so block boundaries never cut a camera.  Grid = (lower-triangular 128x128 output tiles) x (point
+// chunks).  One workgroup = 13 waves with fixed roles:
+//   * 5 producer waves: thread (which, point, camera slot) looks its observation up in the slot table
+//     (slot_obs[p][cam] = observation index or -1), reads the 16 B key and the point, re-derives
+//     Jp, Jx, W = Jp^T Jx and Z = W L_p^-T (L_p^-1 comes from ba_linearize, 48 B/point) and writes the
+//     camera's 7x3 block of Z -- or zeros -- to its fixed place in the [k][row] LDS image of the NEXT
+//     slab (8 points = 24 k-columns); the loads of the slab after that are already in flight.
+//   * 8 consumer waves: v_mfma_f64_16x16x4_f64 on the CURRENT slab.  Off-diagonal tiles: each wave
+//     owns 64x32 (4x2 MFMA tiles, 6 ds_read_b64 per 8 MFMAs).  Diagonal tiles: the 36 lower MFMA tiles
+//     are dealt round-robin (5,5,5,5,4,4,4,4: every SIMD gets 9), the 28 upper ones are never computed.
+// One __syncthreads per slab hands the double-buffered LDS image over.  A operand: lane l holds
+// A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
+// Partial tiles go to per-(chunk, tile) slabs (plain stores), summed into S by ba_schur_reduce_kernel.
 // ---------------------------------------------------------------------------------------------
 typedef double double4_ __attribute__((ext_vector_type(4)));
 
@@ -66,83 +72,208 @@ constexpr int RB = 128;         // padded rows per block
 constexpr int SP = 8;           // points per LDS slab
 constexpr int KSL = 3 * SP;     // k-columns per slab
 constexpr int ZLD = RB + 16;    // row pitch = 16 (mod 32) doubles: the k-rows of one ds_read_b64 hit disjoint banks
+constexpr int N_CONS = 8;       // consumer (MFMA) waves
+constexpr int N_PROD = 5;       // producer waves: 320 threads >= 2 * SP * CB = 288 staging tasks
+constexpr int SCHUR_THREADS = 64 * (N_CONS + N_PROD);
+constexpr int STAGE = KSL * ZLD;   // doubles per LDS image
 
-__global__ __launch_bounds__(512, 4) void ba_schur_mfma_kernel(BaDev d, const int* __restrict__ slot_obs, int vpad,
-                                                            double* __restrict__ ws, int pts_per_chunk) {
-  __shared__ double za[KSL][ZLD];     // Z^T slab restricted to the tile's row block
-  __shared__ double zb[KSL][ZLD];     // ... and to its column block (unused on diagonal tiles)
-  int tile = blockIdx.x, ti = 0;
-  while (tile >= ti + 1) { tile -= ti + 1; ++ti; }
-  const int tj = tile;                   // ti >= tj
-  const bool diag = ti == tj;
-  const int chunk = blockIdx.y;
-  const int p_beg = chunk * pts_per_chunk;
-  const int p_end = min(d.N, p_beg + pts_per_chunk);
+struct SlabIn {     // what one producer task needs for one slab
+  int o;            // observation index or -1
+  double u, v, X, Y, Z, li[6];
+};
+
+// The slot lookup and the loads that depend on it are issued in DIFFERENT slabs (slot two slabs ahead,
+// data one slab ahead), so no load latency is ever exposed on the producers' per-slab path.
+__device__ __forceinline__ int producer_slot(const BaDev& d, const int* __restrict__ slot_obs, int vpad, int p, int p_end,
+                                             int cam) {
+  return (p < p_end && cam < d.V) ? slot_obs[(size_t)p * vpad + cam] : -1;
+}
+
+__device__ __forceinline__ void producer_fetch(const BaDev& d, int o, int p, SlabIn& in) {
+  in.o = o;
+  if (o >= 0) {
+    in.u = d.u[o]; in.v = d.v[o];
+    in.X = d.px[p]; in.Y = d.py[p]; in.Z = d.pz[p];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in.li[k] = d.lip[(size_t)p * 6 + k];
+  }
+}
+
+__device__ __forceinline__ void producer_emit(const SlabIn& in, const double* __restrict__ cam_lds, int quirks,
+                                              double* __restrict__ dst /* &image[3*pl][7*cs] */) {
+  double z[21];
+  if (in.o >= 0) {
+    CamPrep c;
+    double* cd = reinterpret_cast<double*>(&c);
+#pragma unroll
+    for (int k = 0; k < 19; ++k) cd[k] = cam_lds[k];
+    double pc[3], Jp[14], Jx[6];
+    project_cam(c, in.X, in.Y, in.Z, 1.0, pc);
+    jac_cam(c, in.X, in.Y, in.Z, pc, quirks, Jp);
+    jac_pt_cam(c, pc, Jx);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const double w0 = Jp[i] * Jx[0] + Jp[7 + i] * Jx[3];
+      const double w1 = Jp[i] * Jx[1] + Jp[7 + i] * Jx[4];
+      const double w2 = Jp[i] * Jx[2] + Jp[7 + i] * Jx[5];
+      z[3 * i + 0] = w0 * in.li[0];
+      z[3 * i + 1] = w0 * in.li[1] + w1 * in.li[2];
+      z[3 * i + 2] = w0 * in.li[3] + w1 * in.li[4] + w2 * in.li[5];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 21; ++e) z[e] = 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < 21; ++e) dst[(e % 3) * ZLD + e / 3] = z[e];
+}
+
+// Slab hand-over barrier.  __syncthreads() would also wait for vmcnt(0) and so drain the producers'
+// prefetch of the slab after next; here only the LDS traffic has to be complete.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool DIAG>
+__device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int quirks, const int* __restrict__ slot_obs,
+                                                int vpad, double* __restrict__ slab, int ti, int tj, int p_beg,
+                                                int p_end, double* __restrict__ img /*[2 stages][2][STAGE]*/,
+                                                double* __restrict__ cam_lds /*[2][CB][19]*/) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // this wave's 64x32 part
+  const bool consumer = wave < N_CONS;
   const int lr = lane & 15, lk = lane >> 4;
-  const bool active = !(diag && wr == 0 && wc >= 64);
-  const size_t M = (size_t)d.M;
 
-  double4_ acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = double4_{0, 0, 0, 0};
-
-  for (int t = tid; t < KSL * ZLD; t += 512) {     // padding rows 126,127 (+pitch pad) stay zero for good
-    (&za[0][0])[t] = 0.0;
-    (&zb[0][0])[t] = 0.0;
+  // ---- one-time LDS setup: zero both stage images (padding rows stay zero), stage the cameras of both blocks
+  for (int t = tid; t < 4 * STAGE; t += SCHUR_THREADS) img[t] = 0.0;
+  {
+    const double* gprep = reinterpret_cast<const double*>(d.prep[cur]);
+    for (int t = tid; t < 2 * CB * 19; t += SCHUR_THREADS) {
+      const int which = t / (CB * 19), rem = t - which * (CB * 19);
+      const int cam = (which ? tj : ti) * CB + rem / 19;
+      cam_lds[t] = cam < d.V ? gprep[(size_t)cam * 19 + rem % 19] : 0.0;
+    }
   }
   __syncthreads();
 
-  const int ntask = (diag ? 1 : 2) * SP * CB;
-  for (int ps = p_beg; ps < p_end; ps += SP) {
-    for (int t = tid; t < ntask; t += 512) {
-      const int which = t / (SP * CB);
-      const int tt = t - which * (SP * CB);
-      const int pl = tt / CB, cs = tt - pl * CB;
-      const int p = ps + pl;
-      const int cam = (which ? tj : ti) * CB + cs;
-      const int o = (p < p_end) ? slot_obs[(size_t)p * vpad + cam] : -1;
-      double(*dst)[ZLD] = which ? zb : za;
-      double z[21];
-#pragma unroll
-      for (int e = 0; e < 21; ++e) z[e] = (o >= 0) ? d.Z[e * M + o] : 0.0;
-#pragma unroll
-      for (int e = 0; e < 21; ++e) dst[3 * pl + e % 3][7 * cs + e / 3] = z[e];
+  // Producer and consumer waves run DIFFERENT loops with the same number of barriers, so the register
+  // allocator sees max(producer, consumer) pressure instead of their sum.
+  if (!consumer) {
+    constexpr int NTASK = (DIAG ? 1 : 2) * SP * CB;
+    const int ptid = tid - 64 * N_CONS;
+    const bool has_task = ptid < NTASK;
+    const int which = has_task ? ptid / (SP * CB) : 0;
+    const int tt = ptid - which * (SP * CB);
+    const int pl = has_task ? tt / CB : 0, cs = has_task ? tt - pl * CB : 0;
+    const int cam = (which ? tj : ti) * CB + cs;
+    const double* my_cam = cam_lds + (which * CB + cs) * 19;
+    const int dst_off = which * STAGE + 3 * pl * ZLD + 7 * cs;
+    SlabIn in;
+    in.o = -1;
+    int o_next = -1;
+    // prologue: image 0 <- slab 0; data of slab 1 and slot of slab 2 go in flight
+    if (has_task) {
+      producer_fetch(d, producer_slot(d, slot_obs, vpad, p_beg + pl, p_end, cam), p_beg + pl, in);
+      o_next = producer_slot(d, slot_obs, vpad, p_beg + SP + pl, p_end, cam);
+      producer_emit(in, my_cam, quirks, img + dst_off);
+      producer_fetch(d, o_next, p_beg + SP + pl, in);
+      o_next = producer_slot(d, slot_obs, vpad, p_beg + 2 * SP + pl, p_end, cam);
     }
-    __syncthreads();
-    if (active) {
-      const double(*zcol)[ZLD] = diag ? za : zb;
+    lds_barrier();
+    int stage = 0;
+    for (int ps = p_beg; ps < p_end; ps += SP, stage ^= 1) {
+      if (has_task && ps + SP < p_end) {
+        // image stage^1 <- slab ps+SP (data loaded one slab ago); data of slab ps+2SP (its slot was
+        // loaded one slab ago) and slot of slab ps+3SP go in flight
+        producer_emit(in, my_cam, quirks, img + (stage ^ 1) * 2 * STAGE + dst_off);
+        producer_fetch(d, o_next, ps + 2 * SP + pl, in);
+        o_next = producer_slot(d, slot_obs, vpad, ps + 3 * SP + pl, p_end, cam);
+      }
+      lds_barrier();
+    }
+    return;
+  }
+
+  // ---- consumer waves
+  double4_ acc[8];
 #pragma unroll
-      for (int k0 = 0; k0 < KSL; k0 += 4) {
-        const int kk = k0 + lk;
+  for (int s = 0; s < 8; ++s) acc[s] = double4_{0, 0, 0, 0};
+  int sx[5] = {0, 0, 0, 0, 0}, sy[5] = {0, 0, 0, 0, 0};
+  int nsub = 0;
+  if (DIAG) {
+    for (int s = 0; s < 5; ++s) {
+      const int idx = wave + N_CONS * s;
+      if (idx < 36) {
+        int x = 0;
+        while ((x + 1) * (x + 2) / 2 <= idx) ++x;
+        sx[s] = __builtin_amdgcn_readfirstlane(x);
+        sy[s] = __builtin_amdgcn_readfirstlane(idx - x * (x + 1) / 2);
+        nsub = s + 1;
+      }
+    }
+    nsub = __builtin_amdgcn_readfirstlane(nsub);
+  }
+  const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // off-diagonal tiles: this wave's 64x32 part
+  lds_barrier();                                           // prologue barrier (image 0 ready)
+  int stage = 0;
+  for (int ps = p_beg; ps < p_end; ps += SP, stage ^= 1) {
+    const double* za = img + stage * 2 * STAGE;
+    const double* zc = DIAG ? za : za + STAGE;
+#pragma unroll
+    for (int k0 = 0; k0 < KSL; k0 += 4) {
+      const double* ra = za + (k0 + lk) * ZLD + lr;
+      const double* rc = zc + (k0 + lk) * ZLD + lr;
+      if (DIAG) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+          if (s < nsub) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[16 * sx[s]], rc[16 * sy[s]], acc[s], 0, 0, 0);
+      } else {
         double a[4], b[2];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) a[x] = za[kk][wr + 16 * x + lr];
+        for (int x = 0; x < 4; ++x) a[x] = ra[wr + 16 * x];
 #pragma unroll
-        for (int y = 0; y < 2; ++y) b[y] = zcol[kk][wc + 16 * y + lr];
+        for (int y = 0; y < 2; ++y) b[y] = rc[wc + 16 * y];
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-          for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < 2; ++y)
+            acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[2 * x + y], 0, 0, 0);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
-  double* slab = ws + ((size_t)chunk * gridDim.x + blockIdx.x) * (RB * RB);
+  if (DIAG) {
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+    for (int s = 0; s < 5; ++s)
+      if (s < nsub) {
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wr + 16 * x + lk + 4 * r;
-        const int col = wc + 16 * y + lr;
-        slab[row * RB + col] = acc[x][y][r];
+        for (int r = 0; r < 4; ++r) slab[(16 * sx[s] + lk + 4 * r) * RB + 16 * sy[s] + lr] = acc[s][r];
       }
+  } else {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(wr + 16 * x + lk + 4 * r) * RB + wc + 16 * y + lr] = acc[2 * x + y][r];
+  }
 }
+
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, int cur, int quirks,
+                                                                    const int* __restrict__ slot_obs, int vpad,
+                                                                    double* __restrict__ ws, int pts_per_chunk) {
+  extern __shared__ double lds_dyn[];
+  double* img = lds_dyn;                        // [2 stages][za, zb][KSL][ZLD]
+  double* cam_lds = lds_dyn + 4 * STAGE;        // [2 blocks][CB][19]
+  int tile = blockIdx.x, ti = 0;
+  while (tile >= ti + 1) { tile -= ti + 1; ++ti; }
+  const int tj = tile;                   // ti >= tj
+  const int chunk = blockIdx.y;
+  const int p_beg = chunk * pts_per_chunk;
+  const int p_end = min(d.N, p_beg + pts_per_chunk);
+  double* slab = ws + ((size_t)chunk * gridDim.x + blockIdx.x) * (RB * RB);
+  if (ti == tj) schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, tj, p_beg, p_end, img, cam_lds);
+  else schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, tj, p_beg, p_end, img, cam_lds);
+}
+
+constexpr size_t kSchurLdsBytes = sizeof(double) * (4 * STAGE + 2 * CB * 19);
 
 // S(lower) -= sum over chunks of the slabs, un-padding block coordinates (block b, row r) -> camera
 // b*CB + r/7, parameter r%7.  One thread per padded tile element.
@@ -161,9 +292,13 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   if (cam_r >= d.V || cam_c >= d.V) return;
   const int row = 7 * cam_r + r % 7, col = 7 * cam_c + c % 7;
   if (col > row) return;
+  // blockIdx.y slices the chunk range: 4x the loads in flight; one f64 atomic per slice and element
+  const int per = (chunks + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
   double s = 0;
-  for (int k = 0; k < chunks; ++k) s += ws[((size_t)k * ntiles + tile_id) * (RB * RB) + e];
-  d.red[(size_t)row * d.ld + col] -= s;
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) s += ws[((size_t)k * ntiles + tile_id) * (RB * RB) + e];
+  if (s != 0.0) atomicAdd(&d.red[(size_t)row * d.ld + col], -s);
 }
 
 static int schur_nblk(const BaDev& d) { return (d.V + CB - 1) / CB; }
@@ -173,7 +308,7 @@ int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx) {
   const BaDev& d = p->dev;
   const int nblk = schur_nblk(d);
   const int ntiles = nblk * (nblk + 1) / 2;
-  // ~2 workgroups of 8 waves per CU; chunks are whole slabs
+  // one 13-wave workgroup per CU (116 KB of LDS each); two rounds so the tail is short; chunks are whole slabs
   int chunks = std::max(1, (2 * ctx().num_cus + ntiles - 1) / ntiles);
   int ppc = (d.N + chunks - 1) / std::max(1, chunks);
   ppc = std::max(SP, ((ppc + SP - 1) / SP) * SP);
@@ -193,10 +328,12 @@ int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx) {
   for (int pt = 0; pt < d.N; ++pt)
     for (int o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) slot[(size_t)pt * p->schur_vpad + cam_idx[o]] = o;
   SFM_HIP(hipMemcpy(p->schur_slot, slot.data(), slot_bytes, hipMemcpyHostToDevice));
+  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
   return SFM_OK;
 }
 
-static bool use_mfma(const sfm_ba_problem* p) {
+bool ba_schur_uses_mfma(const sfm_ba_problem* p) {
   if (!p->schur_mfma_ok) return false;
   if (p->schur_mode == SFM_SCHUR_MFMA) return true;
   if (p->schur_mode == SFM_SCHUR_PAIRS) return false;
@@ -212,13 +349,14 @@ static bool use_mfma(const sfm_ba_problem* p) {
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return SFM_OK;
-  if (use_mfma(p)) {
+  if (ba_schur_uses_mfma(p)) {
     const int nblk = schur_nblk(d);
     const int ntiles = nblk * (nblk + 1) / 2;
     dim3 grid(ntiles, p->schur_chunks);
     double* ws = static_cast<double*>(p->schur_ws);
-    ba_schur_mfma_kernel<<<grid, 512, 0, s>>>(d, p->schur_slot, p->schur_vpad, ws, p->schur_pts_per_chunk);
-    ba_schur_reduce_kernel<<<(ntiles * RB * RB + 255) / 256, 256, 0, s>>>(d, ws, ntiles, p->schur_chunks);
+    ba_schur_mfma_kernel<<<grid, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, p->cur, p->quirks, p->schur_slot, p->schur_vpad, ws,
+                                                                      p->schur_pts_per_chunk);
+    ba_schur_reduce_kernel<<<dim3((ntiles * RB * RB + 255) / 256, 4), 256, 0, s>>>(d, ws, ntiles, p->schur_chunks);
   } else {
     const size_t lds = sizeof(double) * 21 * (size_t)std::max(1, p->max_track);
     if (lds > 64 * 1024) {

@@ -22,6 +22,8 @@ step 120 "$out/smoke.log" python __graft_entry__.py smoke
 tail -2 "$out/smoke.log"
 step 240 "$out/bench.log" python bench.py --steps 20 --warmup 3
 tail -1 "$out/bench.log"
+step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
+tail -1 "$out/bench_tri_pnp.log"
 step 240 "$out/bench_pairs.log" python bench.py --steps 5 --warmup 1 --schur pairs --no-cpu-baseline
 tail -1 "$out/bench_pairs.log"
 step 300 "$out/rocprof.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
