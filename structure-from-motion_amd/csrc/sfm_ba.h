@@ -60,8 +60,6 @@ struct sfm_ba_problem {
   int* schur_slot = nullptr;     // [N][schur_vpad] observation index of (point, camera) or -1
   int schur_vpad = 0;
   bool schur_mfma_ok = false;
-  int schur_chunks = 0;
-  int schur_pts_per_chunk = 0;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 

@@ -256,67 +256,109 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
   }
 }
 
+// Work split of the MFMA product.  A diagonal tile issues 9 MFMAs per SIMD and k-step, an
+// off-diagonal one 16, so diagonal tiles get proportionally longer point chunks: every workgroup then
+// carries the same MFMA load and the ~2 x CUs workgroups finish in two even rounds.  Workgroup w:
+//   w <  n_off * chunks_off : off-diagonal tile w / chunks_off (pairs ti > tj in row-major order)
+//   else                    : diagonal tile (w - n_off * chunks_off) / chunks_diag
+// and its partial tile goes to slab w.
+struct SchurPlan {
+  int nblk, n_off;
+  int chunks_off, ppc_off;      // chunks per off-diagonal tile, points per chunk
+  int chunks_diag, ppc_diag;
+};
+
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, int cur, int quirks,
                                                                     const int* __restrict__ slot_obs, int vpad,
-                                                                    double* __restrict__ ws, int pts_per_chunk) {
+                                                                    double* __restrict__ ws, SchurPlan plan) {
   extern __shared__ double lds_dyn[];
   double* img = lds_dyn;                        // [2 stages][za, zb][KSL][ZLD]
   double* cam_lds = lds_dyn + 4 * STAGE;        // [2 blocks][CB][19]
-  int tile = blockIdx.x, ti = 0;
-  while (tile >= ti + 1) { tile -= ti + 1; ++ti; }
-  const int tj = tile;                   // ti >= tj
-  const int chunk = blockIdx.y;
-  const int p_beg = chunk * pts_per_chunk;
-  const int p_end = min(d.N, p_beg + pts_per_chunk);
-  double* slab = ws + ((size_t)chunk * gridDim.x + blockIdx.x) * (RB * RB);
-  if (ti == tj) schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, tj, p_beg, p_end, img, cam_lds);
-  else schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, tj, p_beg, p_end, img, cam_lds);
+  const int w = blockIdx.x;
+  const int off_wgs = plan.n_off * plan.chunks_off;
+  double* slab = ws + (size_t)w * (RB * RB);
+  if (w < off_wgs) {
+    int t = w / plan.chunks_off, ti = 1;
+    const int chunk = w - t * plan.chunks_off;
+    while (t >= ti) { t -= ti; ++ti; }           // t-th pair (ti, tj) with ti > tj
+    const int p_beg = chunk * plan.ppc_off;
+    const int p_end = min(d.N, p_beg + plan.ppc_off);
+    schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, t, p_beg, p_end, img, cam_lds);
+  } else {
+    const int w2 = w - off_wgs;
+    const int ti = w2 / plan.chunks_diag;
+    const int chunk = w2 - ti * plan.chunks_diag;
+    const int p_beg = chunk * plan.ppc_diag;
+    const int p_end = min(d.N, p_beg + plan.ppc_diag);
+    schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, ti, p_beg, p_end, img, cam_lds);
+  }
 }
 
 constexpr size_t kSchurLdsBytes = sizeof(double) * (4 * STAGE + 2 * CB * 19);
 
-// S(lower) -= sum over chunks of the slabs, un-padding block coordinates (block b, row r) -> camera
-// b*CB + r/7, parameter r%7.  One thread per padded tile element.
-__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const double* __restrict__ ws, int ntiles,
-                                                              int chunks) {
+// S(lower) -= sum over the tile's chunk slabs, un-padding block coordinates (block b, row r) -> camera
+// b*CB + r/7, parameter r%7.  One thread per padded tile element; blockIdx.y slices the chunk range
+// (more loads in flight), one f64 atomic per slice and element.
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan) {
+  const int ntiles = plan.n_off + plan.nblk;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ntiles * RB * RB) return;
-  int tile = idx / (RB * RB);
+  const int tile = idx / (RB * RB);
   const int e = idx - tile * (RB * RB);
-  const int tile_id = tile;
-  int ti = 0;
-  while (tile >= ti + 1) { tile -= ti + 1; ++ti; }
+  int ti, tj, first, chunks;
+  if (tile < plan.n_off) {
+    int t = tile;
+    ti = 1;
+    while (t >= ti) { t -= ti; ++ti; }
+    tj = t;
+    first = tile * plan.chunks_off;
+    chunks = plan.chunks_off;
+  } else {
+    ti = tj = tile - plan.n_off;
+    first = plan.n_off * plan.chunks_off + ti * plan.chunks_diag;
+    chunks = plan.chunks_diag;
+  }
   const int r = e / RB, c = e - r * RB;
   if (r >= 7 * CB || c >= 7 * CB) return;
-  const int cam_r = ti * CB + r / 7, cam_c = tile * CB + c / 7;
+  const int cam_r = ti * CB + r / 7, cam_c = tj * CB + c / 7;
   if (cam_r >= d.V || cam_c >= d.V) return;
   const int row = 7 * cam_r + r % 7, col = 7 * cam_c + c % 7;
   if (col > row) return;
-  // blockIdx.y slices the chunk range: 4x the loads in flight; one f64 atomic per slice and element
   const int per = (chunks + gridDim.y - 1) / gridDim.y;
   const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
   double s = 0;
 #pragma unroll 4
-  for (int k = k0; k < k1; ++k) s += ws[((size_t)k * ntiles + tile_id) * (RB * RB) + e];
+  for (int k = k0; k < k1; ++k) s += ws[(size_t)(first + k) * (RB * RB) + e];
   if (s != 0.0) atomicAdd(&d.red[(size_t)row * d.ld + col], -s);
 }
 
-static int schur_nblk(const BaDev& d) { return (d.V + CB - 1) / CB; }
+static SchurPlan make_plan(const BaDev& d) {
+  SchurPlan pl;
+  pl.nblk = (d.V + CB - 1) / CB;
+  pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
+  const int slabs = std::max(1, (d.N + SP - 1) / SP);
+  // target ~2 workgroups per CU in total, chunks_diag : chunks_off = 9 : 16
+  const double target = 2.0 * ctx().num_cus;
+  const double a = target / (pl.n_off + (9.0 / 16.0) * pl.nblk);
+  auto fit = [&](double want, int& chunks, int& ppc) {
+    int c = std::max(1, std::min(slabs, (int)(want + 0.5)));
+    const int slabs_per = (slabs + c - 1) / c;
+    ppc = slabs_per * SP;
+    chunks = (slabs + slabs_per - 1) / slabs_per;
+  };
+  fit(a, pl.chunks_off, pl.ppc_off);
+  fit(a * 9.0 / 16.0, pl.chunks_diag, pl.ppc_diag);
+  if (pl.n_off == 0) { pl.chunks_off = 0; pl.ppc_off = SP; }
+  return pl;
+}
 
 // Plan of the MFMA product: chunking of the points, slab workspace and the slot table.
 int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx) {
   const BaDev& d = p->dev;
-  const int nblk = schur_nblk(d);
-  const int ntiles = nblk * (nblk + 1) / 2;
-  // one 13-wave workgroup per CU (116 KB of LDS each); two rounds so the tail is short; chunks are whole slabs
-  int chunks = std::max(1, (2 * ctx().num_cus + ntiles - 1) / ntiles);
-  int ppc = (d.N + chunks - 1) / std::max(1, chunks);
-  ppc = std::max(SP, ((ppc + SP - 1) / SP) * SP);
-  chunks = std::max(1, (d.N + ppc - 1) / ppc);
-  p->schur_chunks = chunks;
-  p->schur_pts_per_chunk = ppc;
-  p->schur_vpad = nblk * CB;
-  const size_t ws_bytes = sizeof(double) * (size_t)chunks * ntiles * RB * RB;
+  const SchurPlan pl = make_plan(d);
+  const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+  p->schur_vpad = pl.nblk * CB;
+  const size_t ws_bytes = sizeof(double) * (size_t)wgs * RB * RB;
   const size_t slot_bytes = sizeof(int) * (size_t)std::max(1, d.N) * p->schur_vpad;
   // the dense path is only ever chosen when it is cheaper than the pair path; do not reserve
   // gigabytes for scenes that will never take it
@@ -350,13 +392,12 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return SFM_OK;
   if (ba_schur_uses_mfma(p)) {
-    const int nblk = schur_nblk(d);
-    const int ntiles = nblk * (nblk + 1) / 2;
-    dim3 grid(ntiles, p->schur_chunks);
+    const SchurPlan pl = make_plan(d);
+    const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    const int ntiles = pl.n_off + pl.nblk;
     double* ws = static_cast<double*>(p->schur_ws);
-    ba_schur_mfma_kernel<<<grid, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, p->cur, p->quirks, p->schur_slot, p->schur_vpad, ws,
-                                                                      p->schur_pts_per_chunk);
-    ba_schur_reduce_kernel<<<dim3((ntiles * RB * RB + 255) / 256, 4), 256, 0, s>>>(d, ws, ntiles, p->schur_chunks);
+    ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, p->cur, p->quirks, p->schur_slot, p->schur_vpad, ws, pl);
+    ba_schur_reduce_kernel<<<dim3((ntiles * RB * RB + 255) / 256, 4), 256, 0, s>>>(d, ws, pl);
   } else {
     const size_t lds = sizeof(double) * 21 * (size_t)std::max(1, p->max_track);
     if (lds > 64 * 1024) {
