@@ -47,6 +47,7 @@ extern "C" {
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over zero-filled LDS tiles */
 
 #define SFM_OPT_SCHUR        1
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 2 no producer math, 4 no producer loads); results are wrong when set */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */

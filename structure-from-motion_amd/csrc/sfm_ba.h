@@ -53,6 +53,7 @@ struct sfm_ba_problem {
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
   int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight (the Schur producers re-derive it)
+  int debug = 0;             // SFM_OPT_DEBUG: profiling ablations (results are wrong when set)
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)

@@ -762,6 +762,9 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
       if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
       p->schur_mode = value;
       return SFM_OK;
+    case SFM_OPT_DEBUG:
+      p->debug = value;
+      return SFM_OK;
     case SFM_OPT_TIMING:
       p->timing = value;   // bit k set = time kernel class k
       return SFM_OK;

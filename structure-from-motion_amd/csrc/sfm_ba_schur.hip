@@ -111,14 +111,18 @@ __device__ __forceinline__ void producer_emit(const SlabIn& in, const double* __
     project_cam(c, in.X, in.Y, in.Z, 1.0, pc);
     jac_cam(c, in.X, in.Y, in.Z, pc, quirks, Jp);
     jac_pt_cam(c, pc, Jx);
+    // Z = (Jp^T Jx) Li^T = Jp^T (Jx Li^T): 2x3 product first, then 7 rows of 2 FMAs x 3
+    double m0[3], m1[3];
+    m0[0] = Jx[0] * in.li[0];
+    m0[1] = Jx[0] * in.li[1] + Jx[1] * in.li[2];
+    m0[2] = Jx[0] * in.li[3] + Jx[1] * in.li[4] + Jx[2] * in.li[5];
+    m1[0] = Jx[3] * in.li[0];
+    m1[1] = Jx[3] * in.li[1] + Jx[4] * in.li[2];
+    m1[2] = Jx[3] * in.li[3] + Jx[4] * in.li[4] + Jx[5] * in.li[5];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const double w0 = Jp[i] * Jx[0] + Jp[7 + i] * Jx[3];
-      const double w1 = Jp[i] * Jx[1] + Jp[7 + i] * Jx[4];
-      const double w2 = Jp[i] * Jx[2] + Jp[7 + i] * Jx[5];
-      z[3 * i + 0] = w0 * in.li[0];
-      z[3 * i + 1] = w0 * in.li[1] + w1 * in.li[2];
-      z[3 * i + 2] = w0 * in.li[3] + w1 * in.li[4] + w2 * in.li[5];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) z[3 * i + j] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
     }
   } else {
 #pragma unroll
@@ -136,7 +140,7 @@ template <bool DIAG>
 __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int quirks, const int* __restrict__ slot_obs,
                                                 int vpad, double* __restrict__ slab, int ti, int tj, int p_beg,
                                                 int p_end, double* __restrict__ img /*[2 stages][2][STAGE]*/,
-                                                double* __restrict__ cam_lds /*[2][CB][19]*/) {
+                                                double* __restrict__ cam_lds /*[2][CB][19]*/, int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool consumer = wave < N_CONS;
   const int lr = lane & 15, lk = lane >> 4;
@@ -156,6 +160,11 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
   // Producer and consumer waves run DIFFERENT loops with the same number of barriers, so the register
   // allocator sees max(producer, consumer) pressure instead of their sum.
   if (!consumer) {
+    // MFMA-f64 and VALU-f64 share one FP64 pipe per SIMD and the (older) consumer waves always have an
+    // MFMA ready: at equal priority the producers only get the pipe once the consumers sit at the slab
+    // barrier, which serialises the two phases.  With raised priority the producers' short dependent
+    // chains slot in between MFMAs and the slab is ready before the consumers need it.
+    __builtin_amdgcn_s_setprio(3);
     constexpr int NTASK = (DIAG ? 1 : 2) * SP * CB;
     const int ptid = tid - 64 * N_CONS;
     const bool has_task = ptid < NTASK;
@@ -182,9 +191,11 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
       if (has_task && ps + SP < p_end) {
         // image stage^1 <- slab ps+SP (data loaded one slab ago); data of slab ps+2SP (its slot was
         // loaded one slab ago) and slot of slab ps+3SP go in flight
-        producer_emit(in, my_cam, quirks, img + (stage ^ 1) * 2 * STAGE + dst_off);
-        producer_fetch(d, o_next, ps + 2 * SP + pl, in);
-        o_next = producer_slot(d, slot_obs, vpad, ps + 3 * SP + pl, p_end, cam);
+        if (!(dbg & 2)) producer_emit(in, my_cam, quirks, img + (stage ^ 1) * 2 * STAGE + dst_off);
+        if (!(dbg & 4)) {
+          producer_fetch(d, o_next, ps + 2 * SP + pl, in);
+          o_next = producer_slot(d, slot_obs, vpad, ps + 3 * SP + pl, p_end, cam);
+        }
       }
       lds_barrier();
     }
@@ -216,6 +227,7 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
   for (int ps = p_beg; ps < p_end; ps += SP, stage ^= 1) {
     const double* za = img + stage * 2 * STAGE;
     const double* zc = DIAG ? za : za + STAGE;
+    if (!(dbg & 1))
 #pragma unroll
     for (int k0 = 0; k0 < KSL; k0 += 4) {
       const double* ra = za + (k0 + lk) * ZLD + lr;
@@ -266,6 +278,7 @@ struct SchurPlan {
   int nblk, n_off;
   int chunks_off, ppc_off;      // chunks per off-diagonal tile, points per chunk
   int chunks_diag, ppc_diag;
+  int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 2 = no producer math, 4 = no producer loads
 };
 
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, int cur, int quirks,
@@ -283,14 +296,14 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, i
     while (t >= ti) { t -= ti; ++ti; }           // t-th pair (ti, tj) with ti > tj
     const int p_beg = chunk * plan.ppc_off;
     const int p_end = min(d.N, p_beg + plan.ppc_off);
-    schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, t, p_beg, p_end, img, cam_lds);
+    schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, t, p_beg, p_end, img, cam_lds, plan.dbg);
   } else {
     const int w2 = w - off_wgs;
     const int ti = w2 / plan.chunks_diag;
     const int chunk = w2 - ti * plan.chunks_diag;
     const int p_beg = chunk * plan.ppc_diag;
     const int p_end = min(d.N, p_beg + plan.ppc_diag);
-    schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, ti, p_beg, p_end, img, cam_lds);
+    schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, ti, p_beg, p_end, img, cam_lds, plan.dbg);
   }
 }
 
@@ -334,6 +347,7 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
 
 static SchurPlan make_plan(const BaDev& d) {
   SchurPlan pl;
+  pl.dbg = 0;
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
   const int slabs = std::max(1, (d.N + SP - 1) / SP);
@@ -392,7 +406,8 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return SFM_OK;
   if (ba_schur_uses_mfma(p)) {
-    const SchurPlan pl = make_plan(d);
+    SchurPlan pl = make_plan(d);
+    pl.dbg = p->debug;
     const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
     const int ntiles = pl.n_off + pl.nblk;
     double* ws = static_cast<double*>(p->schur_ws);

@@ -367,3 +367,74 @@ def test_processors_drop_in(hip, sfm, oracle, capsys):
     for cidx in range(nv):
         assert rel(views[cidx].loc[:, 0], g6["cams_it3"][cidx, 0:3]) < TOL
         assert rel(sfm.geometry.rotation_to_quaternion(views[cidx].rot)[:, 0], g6["cams_it3"][cidx, 3:7]) < TOL
+
+
+# ---- paths the headline config does not touch --------------------------------------------------------
+@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+def test_ba_many_cameras_global_accumulator_path(hip, oracle, sfm, mode):
+    """160 cameras: the per-camera accumulators no longer fit the 64 KB LDS budget of ba_linearize /
+    ba_backsub (global-atomic path), the MFMA product has 9 camera blocks (45 tiles) and tracks are
+    short and ragged (8 % visibility)."""
+    sc = sfm.scenes.make_scene(160, 600, 0.08, seed=31)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 2)
+        cams, pts = prob.get_state()
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    assert rel(cams, ocams) < TOL and rel(pts, opts) < TOL
+
+
+def test_ba_auto_mode_picks_a_correct_kernel_on_sparse_scene(hip, oracle, sfm):
+    sc = sfm.scenes.make_scene(60, 2000, 0.1, seed=32)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    cams, pts = hip.ba_solve(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn, sc.cams_init, sc.pts_init, 5.0, 2)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    assert rel(cams, ocams) < TOL and rel(pts, opts) < TOL
+
+
+def test_ba_repeatable_and_state_reset(hip, sfm):
+    """Same problem object, state reset between runs: the MFMA path has no atomics on its inner loop and
+    the reductions it does use commute to ~1 ulp; results must agree to 1e-13 run to run."""
+    sc = sfm.scenes.make_scene(12, 800, 0.5, seed=33)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    runs = []
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        for _ in range(3):
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            runs.append(prob.get_state())
+    for c, p in runs[1:]:
+        assert rel(c, runs[0][0]) < 1e-13 and rel(p, runs[0][1]) < 1e-13
+
+
+def test_tri_many_views_global_projection_path(hip, oracle, sfm):
+    """More views than the LDS staging of the projections holds (512): projections come from global memory."""
+    rng = np.random.default_rng(3)
+    nv, m = 520, 5
+    sc = sfm.scenes.make_scene(3, m, 1.0, seed=34)
+    projs, uv = [], []
+    for v in range(nv):
+        c = v % 3
+        rot = sfm.geometry.quaternion_to_rotation(sc.cams_true[c, 3:7])
+        loc = sc.cams_true[c, 0:3].reshape(3, 1) + rng.normal(0, 1e-3, (3, 1))
+        projs.append(sc.intrinsic @ np.hstack((rot.T, rot.T @ -loc)))
+        uv.append(sc.uv_pix[:, sc.cam_idx == c] + rng.normal(0, 0.1, (2, m)))
+    init = np.vstack((sc.pts_init, np.ones((1, m))))
+    got = hip.tri_nonlinear(np.stack(projs), np.stack(uv), init, 0.5, 5)
+    want = oracle.nonlinear_triangulate_vec(init, projs, uv, 0.5, 5)
+    assert rel(got, want) < TOL
+
+
+def test_pnp_tiny_inputs(hip, oracle):
+    g = load_golden("g5_pnp.npz")
+    for n in (1, 2, 7):
+        uv, x = g["syn1_uv"][:, :n], g["syn1_X"][:, :n]
+        r, c = hip.pnp_nonlinear(uv, x, g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 6)
+        ro, co = oracle.nonlinear_pnp(uv, x, g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 6)
+        assert rel(r, ro) < TOL and rel(c, co) < TOL, n
+    # zero iterations: R(q0) of the normalised initial quaternion and C0 come back (campose:458-459)
+    r, c = hip.pnp_nonlinear(g["syn1_uv"], g["syn1_X"], g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 0)
+    ro, co = oracle.nonlinear_pnp(g["syn1_uv"], g["syn1_X"], g["syn_K"], g["syn1_R0"], g["syn1_C0"], 5, 0)
+    assert rel(r, ro) < 1e-14 and np.array_equal(c, co)
