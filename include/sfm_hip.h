@@ -47,7 +47,7 @@ extern "C" {
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over zero-filled LDS tiles */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 2 no producer math, 4 no producer loads); results are wrong when set */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 2 no producer math, 4 no producer loads: results are wrong when set; 8 = record clock stamps) */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */
@@ -124,6 +124,8 @@ int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
  * synchronises.  *launches may be NULL. */
 int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches);
 int sfm_ba_reset_timing(sfm_ba_problem* p);
+/* Diagnostic: shader-clock stamps written by instrumented kernels when SFM_OPT_DEBUG has bit 8 set. */
+int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n);
 
 /* Multi-GPU split of one iteration (points sharded by rank, cameras replicated):
  *   sfm_ba_linearize_reduce : this rank's partial reduced system [S (P x P, P = 7V padded to

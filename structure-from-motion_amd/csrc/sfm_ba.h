@@ -33,7 +33,9 @@ struct BaDev {
   double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
   double* delta = nullptr;  // [ld] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] Cholesky factors of the diagonal blocks
+  double* ldiag_rd = nullptr;   // [ceil(P/32)][32] reciprocals of their diagonals
   int* status = nullptr;    // [2] first failure code, camera index
+  unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };
 
 struct KernelTimer {

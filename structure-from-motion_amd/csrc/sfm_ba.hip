@@ -310,68 +310,93 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // X = T L_d^-T.  Column j of L_d is published through a 32-double LDS buffer and read back with
 // wave-uniform addresses (LDS broadcast): one ds_read + one FMA per trailing entry, no SGPR hazards.
 // Single wave => its LDS operations execute in order; no barrier is needed.
-__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], double (*colbuf)[NB], int lane) {
-  // Software-pipelined over columns: the two trailing columns the NEXT pivots depend on are updated
-  // through register broadcasts (no LDS round trip on the critical path, which is then
-  // rsqrt -> scale -> broadcast -> fma); the remaining trailing columns stream through the LDS buffer.
+__device__ __forceinline__ double chol_trsm_rows(double (&a)[NB], double (*colbuf)[64], int lane) {
+  // Software-pipelined over columns.  Per column j:
+  //   1. pivot chain: inv = rsqrt(d_jj), scale column j                       (critical path)
+  //   2. deferred bulk update with column j-1, whose entries were read back from LDS one step ago
+  //   3. fast path: the FAST trailing columns the next pivots depend on, through register broadcasts
+  //   4. publish column j in its own LDS row (all 64 lanes store: no exec masking, one basic block) and
+  //      issue the LDS reads whose values step j+1 consumes in (2)
+  // Every LDS row is written once and read once, so there are no WAR hazards for the scheduler to respect.
   constexpr int FAST = 2;
+  double my_inv = 1.0;      // 1 / l_jj for j == lane: the back substitution multiplies by it instead of dividing
+  double lk[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) lk[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const double inv = rsqrt_nr(lane_bcast(a[j], j));
+    my_inv = (lane == j) ? inv : my_inv;
+    if (j > 0) {
+#pragma unroll
+      for (int k = j + FAST; k < NB; ++k) a[k] -= a[j - 1] * lk[k];      // column j-1, entries k >= (j-1)+1+FAST
+    }
     a[j] *= inv;
 #pragma unroll
     for (int k = j + 1; k < NB && k <= j + FAST; ++k) a[k] -= a[j] * lane_bcast(a[j], k);
-    double* cb = colbuf[j & 1];
-    if (lane < NB) cb[lane] = a[j];
-    __builtin_amdgcn_wave_barrier();
+    colbuf[j][lane] = a[j];
 #pragma unroll
-    for (int k = j + 1 + FAST; k < NB; ++k) a[k] -= a[j] * cb[k];
+    for (int k = j + 1 + FAST; k < NB; ++k) lk[k] = colbuf[j][k];
   }
+  return my_inv;
 }
 
+typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int LP = NB + 2;   // LDS pitch 34 doubles: the (row, k) operand reads of v_mfma_f64_16x16x4 hit 32 distinct bank pairs
+
 __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
-  __shared__ double La[NB][NB + 1];   // L[r][j-1]
-  __shared__ double Lb[NB][NB + 1];   // L[c][j-1]
-  __shared__ double Lj[NB][NB + 1];   // L[j][j-1] (column-j blocks with r != j)
+  __shared__ double La[NB][LP];   // L[r][j-1]
+  __shared__ double Lb[NB][LP];   // L[c][j-1]
+  __shared__ double Lj[NB][LP];   // L[j][j-1] (column-j blocks with r != j)
   __shared__ double Tm[NB][NB + 1];
   __shared__ double Dm[NB][NB + 1];
-  __shared__ double colbuf[2][NB];
+  __shared__ double colbuf[NB][64];   // one row per column of the elimination (written once, read once)
   const int P = d.P, ld = d.ld;
   const int nbk = (P + NB - 1) / NB;
   const int c = j + blockIdx.x, r = j + blockIdx.y;
   if (r < c) return;
   const bool is_rhs = r == nbk;
+  // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
+  unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
   double* S = d.red;
   double* rhs = d.red + (size_t)ld * ld;
   const int r0 = r * NB, c0 = c * NB, j0 = j * NB, k0 = (j - 1) * NB;
   const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
+  const int lane = tid & 63, wave = tid >> 6;
   const bool col_j = c == j;
   const bool need_d = col_j && r != j;
-  const bool col_ok = c0 + tj < P;
 
-  // block rows past P (last block) and the 31 unused rows of the rhs block read as zero
-  auto row_ptr = [&](int blk_r0, int i, bool rhs_row) -> const double* {
-    if (rhs_row) return i == 0 ? rhs : nullptr;
-    return (blk_r0 + i < P) ? S + (size_t)(blk_r0 + i) * ld : nullptr;
-  };
+  // This wave's 16x16 part of the 32x32 block, in the C/D layout of v_mfma_f64_16x16x4_f64:
+  // element reg of lane l is (row = 16 sx + (l >> 4) + 4 reg, col = 16 sy + (l & 15)).
+  const int sx = wave >> 1, sy = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ocol = 16 * sy + lr;
+  const bool col_ok = c0 + ocol < P;
 
-  // every global load of the step is issued before the first wait
-  double aT[4], aD[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0}, lj[4] = {0, 0, 0, 0};
+  // Every global load of the step is issued unconditionally and before the first wait: S has ld >= 32 nbk
+  // rows and columns and is zero outside P x P (memset per iteration, never written there), so padded
+  // rows / columns simply read as zero; the 31 non-existent rows of the rhs block are masked by a select.
+  double aT[4], aD[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = ti + 8 * e;
-    const double* pr = row_ptr(r0, i, is_rhs);
-    const double* pc = row_ptr(c0, i, false);
-    const double* pj = row_ptr(j0, i, false);
-    aT[e] = (pr && col_ok) ? pr[c0 + tj] : 0.0;
-    if (need_d) aD[e] = (pj && col_ok) ? pj[j0 + tj] : 0.0;
-    if (j > 0) {
-      la[e] = pr ? pr[k0 + tj] : 0.0;
-      lb[e] = pc ? pc[k0 + tj] : 0.0;
-      if (need_d) lj[e] = pj ? pj[k0 + tj] : 0.0;
-    }
+  for (int g = 0; g < 4; ++g) {
+    const int i = 16 * sx + lk + 4 * g;
+    const double* pr = is_rhs ? rhs : S + (size_t)(r0 + i) * ld;
+    const double t = pr[c0 + ocol];
+    aT[g] = (!is_rhs || i == 0) ? t : 0.0;
+    if (need_d) aD[g] = S[(size_t)(j0 + i) * ld + j0 + ocol];
   }
   if (j > 0) {
+    double la[4], lb[4], lj[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = ti + 8 * e;
+      const double* pr = is_rhs ? rhs : S + (size_t)(r0 + i) * ld;
+      const double a = pr[k0 + tj];
+      la[e] = (!is_rhs || i == 0) ? a : 0.0;
+      lb[e] = S[(size_t)(c0 + i) * ld + k0 + tj];
+      if (need_d) lj[e] = S[(size_t)(j0 + i) * ld + k0 + tj];
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int i = ti + 8 * e;
@@ -380,55 +405,56 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       if (need_d) Lj[i][tj] = lj[e];
     }
     __syncthreads();
-    // k outermost: the column operand Lb[tj][k] is read once per k and reused by the thread's 4 rows; the
-    // row operands La[i][k] are wave-broadcast reads (all 32 lanes of a row share the address)
-    double st[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+    // previous-panel update on the matrix pipe: T -= L[r][j-1] L[c][j-1]^T, D -= L[j][j-1] L[j][j-1]^T.
+    // A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15] = Lb[col][k].
+    chol_f64x4 pT = {0, 0, 0, 0}, pD = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const double b = Lb[tj][k];
+    for (int kk = 0; kk < NB; kk += 4)
+      pT = __builtin_amdgcn_mfma_f64_16x16x4f64(La[16 * sx + lr][kk + lk], Lb[16 * sy + lr][kk + lk], pT, 0, 0, 0);
+    if (need_d) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) st[e] += La[ti + 8 * e][k] * b;
-      if (need_d) {
-        const double bj = Lj[tj][k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sd[e] += Lj[ti + 8 * e][k] * bj;
-      }
+      for (int kk = 0; kk < NB; kk += 4)
+        pD = __builtin_amdgcn_mfma_f64_16x16x4f64(Lj[16 * sx + lr][kk + lk], Lj[16 * sy + lr][kk + lk], pD, 0, 0, 0);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { aT[e] -= st[e]; aD[e] -= sd[e]; }
+    for (int g = 0; g < 4; ++g) { aT[g] -= pT[g]; aD[g] -= pD[g]; }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = ti + 8 * e;
+  for (int g = 0; g < 4; ++g) {
+    const int i = 16 * sx + lk + 4 * g;
     const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
-    double t = (row_ok && col_ok) ? aT[e] : 0.0;
+    double t = (row_ok && col_ok) ? aT[g] : 0.0;
     if (!col_j) {
-      if (row_ok && col_ok) (is_rhs ? rhs : S + (size_t)(r0 + i) * ld)[c0 + tj] = t;
+      if (row_ok && col_ok) (is_rhs ? rhs : S + (size_t)(r0 + i) * ld)[c0 + ocol] = t;
       continue;
     }
     if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
-      if (i == tj) t = col_ok ? t + lambda : 1.0;
-      Dm[i][tj] = t;
-      Tm[i][tj] = 0.0;
+      if (i == ocol) t = col_ok ? t + lambda : 1.0;
+      Dm[i][ocol] = t;
+      Tm[i][ocol] = 0.0;
     } else {
-      Tm[i][tj] = t;
-      double dv = (j0 + i < P && col_ok) ? aD[e] : 0.0;
-      if (i == tj) dv = col_ok ? dv + lambda : 1.0;
-      Dm[i][tj] = dv;
+      Tm[i][ocol] = t;
+      double dv = (j0 + i < P && col_ok) ? aD[g] : 0.0;
+      if (i == ocol) dv = col_ok ? dv + lambda : 1.0;
+      Dm[i][ocol] = dv;
     }
   }
   if (!col_j) return;
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (tid >= 64) return;
-  const int lane = tid;
   double a[NB];
   const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
   const int row = lane & (NB - 1);
 #pragma unroll
   for (int k = 0; k < NB; ++k) a[k] = src[row][k];
-  chol_trsm_rows(a, colbuf, lane);
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+  const double my_inv = chol_trsm_rows(a, colbuf, lane);
+  if (stamp) { asm volatile("" :: "v"(a[NB - 1])); stamp[4] = __builtin_amdgcn_s_memtime(); }
   if (r == j) {
     if (lane < NB) {
+      d.ldiag_rd[(size_t)j * NB + row] = my_inv;
       double* out = d.ldiag + ((size_t)j * NB + row) * NB;
 #pragma unroll
       for (int k = 0; k < NB; ++k) out[k] = (k <= row) ? a[k] : 0.0;
@@ -445,6 +471,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       for (int k = 0; k < NB; ++k) out[k] = a[k];
     }
   }
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
 }
 
 // L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one workgroup:
@@ -452,56 +479,89 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 // (static register indexing; the next block's column is prefetched while all threads fold x_b into
 // the y of the blocks above, 32 independent coalesced loads per thread).  Then the camera update of
 // ba:383-392 and the preparation of the next iteration.
+template <bool Y_LDS>
 __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
+  extern __shared__ double ylds[];     // [ld] working copy of y when it fits (Y_LDS)
   __shared__ double xb[NB];
   const int P = d.P, ld = d.ld;
   const double* S = d.red;
-  double* y = d.red + (size_t)ld * ld;
+  double* yg = d.red + (size_t)ld * ld;
   const int tid = threadIdx.x;
   const int lane = tid & (NB - 1);
   const int nbk = (P + NB - 1) / NB;
+  if (Y_LDS) {
+    for (int i = tid; i < ld; i += blockDim.x) ylds[i] = yg[i];
+  }
+  auto yref = [&](int i) -> double& { return Y_LDS ? ylds[i] : yg[i]; };
+  // wave 0 owns the triangular solves (lane i = column i of L_d, static register indexing, reciprocal
+  // diagonal from the factorisation); waves 1-3 fold x_b into the y of the blocks above, their 32
+  // independent coalesced row loads per thread issued before x_b exists
   double col[NB], rdi = 1.0;
   if (tid < 64) {
     const double* Ld = d.ldiag + (size_t)(nbk - 1) * NB * NB;
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];      // column `lane` of L_d (zero above the diagonal)
+    rdi = d.ldiag_rd[(size_t)(nbk - 1) * NB + lane];
   }
+  __syncthreads();
+  unsigned long long* stamp = (d.stamps && tid == 0) ? d.stamps + 128 : nullptr;
+  const int utid = tid - 64;            // 0..191 for the update waves
   for (int b = nbk - 1; b >= 0; --b) {
     const int c0 = b * NB;
-    if (tid < 64) {
-      double diag = 0.0;
+    if (stamp) stamp[4 * b + 0] = __builtin_amdgcn_s_memtime();
+    double v[2][NB];
+    if (tid >= 64) {
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) diag = (lane == jj) ? col[jj] : diag;    // L_d[lane][lane]
-      rdi = 1.0 / diag;
-      double yi = (c0 + lane < P) ? y[c0 + lane] : 0.0;
+      for (int h = 0; h < 2; ++h) {
+        const int i = utid + h * 192;
+        if (i < c0) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) v[h][k] = S[(size_t)(c0 + k) * ld + i];   // rows >= P are zero (memset, never written)
+        }
+      }
+    } else {
+      double yi = (c0 + lane < P) ? yref(c0 + lane) : 0.0;
       double xi = 0.0;
 #pragma unroll
       for (int jj = NB - 1; jj >= 0; --jj) {
         const double xj = lane_bcast(yi * rdi, jj);
-        if (lane == jj) xi = xj;
+        xi = (lane == jj) ? xj : xi;
         yi -= col[jj] * xj;              // lanes >= jj: col[jj] multiplies a value no longer used
       }
       if (tid < NB) {
         xb[lane] = (c0 + lane < P) ? xi : 0.0;
         if (c0 + lane < P) d.delta[c0 + lane] = xi;
       }
+      if (stamp) stamp[4 * b + 1] = __builtin_amdgcn_s_memtime();
+      if (b > 0) {                       // next diagonal factor; lands during the update below
+        const double* Ld = d.ldiag + (size_t)(b - 1) * NB * NB;
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];
+        rdi = d.ldiag_rd[(size_t)(b - 1) * NB + lane];
+      }
     }
     __syncthreads();
-    if (tid < 64 && b > 0) {             // prefetch the next diagonal factor; lands during the update below
-      const double* Ld = d.ldiag + (size_t)(b - 1) * NB * NB;
+    if (stamp) stamp[4 * b + 2] = __builtin_amdgcn_s_memtime();
+    if (tid >= 64) {
 #pragma unroll
-      for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];
-    }
-    for (int i = tid; i < c0; i += blockDim.x) {
-      double v[NB];
+      for (int h = 0; h < 2; ++h) {
+        const int i = utid + h * 192;
+        if (i < c0) {
+          double s = 0;
 #pragma unroll
-      for (int k = 0; k < NB; ++k) v[k] = S[(size_t)(c0 + k) * ld + i];   // rows >= P are zero (memset, never written)
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) s += v[k] * xb[k];
-      y[i] -= s;
+          for (int k = 0; k < NB; ++k) s += v[h][k] * xb[k];
+          yref(i) -= s;
+        }
+      }
+      for (int i = utid + 384; i < c0; i += 192) {     // more than 384 rows above: plain loop
+        double s = 0;
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) s += S[(size_t)(c0 + k) * ld + i] * xb[k];
+        yref(i) -= s;
+      }
     }
     __syncthreads();
+    if (stamp) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
   }
   for (int c = tid; c < d.V; c += blockDim.x) {
     double cam[7];
@@ -633,7 +693,11 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
     dim3 grid(nbk - j, nbk - j + 1);            // (block column c - j, block row r - j); row nbk = the rhs
     ba_chol_step_kernel<<<grid, 256, 0, s>>>(d, j, lambda);
   }
-  ba_back_solve_kernel<<<1, 256, 0, s>>>(d, p->cur);
+  {
+    const size_t ybytes = sizeof(double) * (size_t)d.ld;
+    if (ybytes <= 48 * 1024) ba_back_solve_kernel<true><<<1, 256, ybytes, s>>>(d, p->cur);
+    else ba_back_solve_kernel<false><<<1, 256, 0, s>>>(d, p->cur);
+  }
   tick(p, SFM_K_SOLVE, false, s);
   SFM_HIP(hipGetLastError());
   const int g = pick_group(p);
@@ -720,6 +784,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
+  BA_ALLOC(d.ldiag_rd, (size_t)((d.P + 31) / 32) * 32);
   BA_ALLOC(d.status, 2);
 #undef BA_ALLOC
   d.red = p->own_red;
@@ -746,7 +811,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.lip, d.lin_ws, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_slot};
+                  d.Z, d.lip, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws, p->schur_slot};
   for (void* q : ptrs) if (q) (void)hipFree(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -764,6 +829,10 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
       return SFM_OK;
     case SFM_OPT_DEBUG:
       p->debug = value;
+      if ((value & 8) && p->dev.stamps == nullptr) {
+        SFM_HIP(hipMalloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
+        SFM_HIP(hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 1024));
+      }
       return SFM_OK;
     case SFM_OPT_TIMING:
       p->timing = value;   // bit k set = time kernel class k
@@ -861,6 +930,14 @@ int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* 
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = t.used;
+  return SFM_OK;
+}
+
+int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n) {
+  SFM_TRY(check_problem(p));
+  if (p->dev.stamps == nullptr || n < 0 || n > 1024) { set_error("debug stamps not enabled (SFM_OPT_DEBUG bit 8)"); return SFM_E_SHAPE; }
+  SFM_HIP(hipStreamSynchronize(ctx().stream));
+  SFM_HIP(hipMemcpy(out, p->dev.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
   return SFM_OK;
 }
 

@@ -26,7 +26,7 @@ EXPORTS = (
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
-    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing",
+    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
 )
@@ -305,3 +305,9 @@ class BaProblem:
 
     def reset_timing(self):
         check(self._lib.sfm_ba_reset_timing(self._h))
+
+    def debug_stamps(self, n=1024):
+        out = np.zeros(n, dtype=np.uint64)
+        self._lib.sfm_ba_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        check(self._lib.sfm_ba_debug_stamps(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n))
+        return out
