@@ -88,6 +88,16 @@ int sfm_tri_nonlinear(int m, int n_views, const double* projs /*[n_views][3][4]*
                       const double* uv /*[n_views][2][m]*/, const double* X_in /*[4][m]*/,
                       double lambda, int iters, double* X_out /*[4][m]*/);
 
+/* ---- TriangulationProcessor.linear_triangulate (triangulation_processor.py:91-157) ------------------ */
+/* DLT: per point the null vector of the (2 n_views x 4) matrix of rows u P[2,:] - P[0,:], v P[2,:] - P[1,:],
+ * divided by its W (streaming Givens QR + one-sided Jacobi SVD per thread). */
+int sfm_tri_linear(int m, int n_views, const double* projs /*[n_views][3][4]*/, const double* uv /*[n_views][2][m]*/,
+                   double* X_out /*[4][m]*/);
+/* TriangulationProcessor.triangulate (triangulation_processor.py:31-88): linear then nonlinear, the
+ * initial points never leave the device. */
+int sfm_triangulate(int m, int n_views, const double* projs /*[n_views][3][4]*/, const double* uv /*[n_views][2][m]*/,
+                    double lambda, int iters, double* X_out /*[4][m]*/);
+
 /* ---- CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459) ----------- */
 int sfm_pnp_nonlinear(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/,
                       const double K[9], const double R0[9], const double C0[3],

@@ -395,11 +395,12 @@ bool ba_schur_uses_mfma(const sfm_ba_problem* p) {
   if (p->schur_mode == SFM_SCHUR_PAIRS) return false;
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return false;
-  // dense cost ~ (7V)^2/2 * 3N MACs; pair cost ~ 49 * sum k(k+1)/2 atomics (~50x dearer each)
+  // Measured on MI355X at C3 (profiles/r01p): the dense product retires ~22 T MACs/s of its (7V)^2/2 * 3N
+  // MACs, the pair kernel ~0.08 T f64 atomic adds/s of its 49 * sum k(k+1)/2 adds: one add costs ~280 MACs.
   const double dense = 0.5 * (double)d.P * d.P * 3.0 * d.N;
   const double kbar = (double)d.M / d.N;
   const double pairs = 49.0 * 0.5 * kbar * (kbar + 1) * d.N;
-  return dense < 40.0 * pairs;
+  return dense < 250.0 * pairs;
 }
 
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {

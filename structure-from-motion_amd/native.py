@@ -24,7 +24,7 @@ KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub")
 EXPORTS = (
     "sfm_version", "sfm_init", "sfm_shutdown", "sfm_set_stream", "sfm_synchronize", "sfm_last_error",
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
-    "sfm_tri_nonlinear", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
+    "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
@@ -86,6 +86,8 @@ def load():
     lib.sfm_ba_reduced_system.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, _ip, _ip, _dp, _dp, _dp,
                                           ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
     lib.sfm_tri_nonlinear.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int, _dp]
+    lib.sfm_tri_linear.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
+    lib.sfm_triangulate.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.c_int, _dp]
     lib.sfm_pnp_nonlinear.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, ctypes.c_int,
                                       ctypes.c_int, _dp, _dp]
     lib.sfm_pnp_nonlinear_batch.argtypes = [ctypes.c_int, _ip, ctypes.c_int, _dp, _dp, _dp, _dp, _dp,
@@ -185,6 +187,24 @@ def tri_nonlinear(projs, uv, x_in, lam, iters):
     nv, m = projs.shape[0], x_in.shape[1]
     out = np.empty((4, m))
     check(load().sfm_tri_nonlinear(m, nv, dptr(projs), dptr(uv), dptr(x_in), float(lam), int(iters), dptr(out)))
+    return out
+
+
+def tri_linear(projs, uv):
+    """DLT triangulation: projs (V,3,4); uv (V,2,m) -> (4,m) with W = 1."""
+    projs = f64(projs); uv = f64(uv)
+    nv, m = projs.shape[0], uv.shape[2]
+    out = np.empty((4, m))
+    check(load().sfm_tri_linear(m, nv, dptr(projs), dptr(uv), dptr(out)))
+    return out
+
+
+def triangulate(projs, uv, lam, iters):
+    """Linear then nonlinear triangulation in one call (initial points stay on the device)."""
+    projs = f64(projs); uv = f64(uv)
+    nv, m = projs.shape[0], uv.shape[2]
+    out = np.empty((4, m))
+    check(load().sfm_triangulate(m, nv, dptr(projs), dptr(uv), float(lam), int(iters), dptr(out)))
     return out
 
 

@@ -76,15 +76,38 @@ class HipTriangulationMixin:
         if num_projs < 2:
             logging.warning('%s : insufficient projections, %d', self.__class__.__name__, num_projs)
             raise ValueError("insufficient projections : {}".format(num_projs))
-        init_3d_pts = self.linear_triangulate(projs, matched_pairs)
-        return self.nonlinear_triangulate(init_3d_pts, projs, matched_pairs, damping_factor, iteration)
+        # linear (tri:85) + nonlinear (tri:86) in one device call: the DLT points never visit the host
+        uv, projs_arr = self._pack_views(projs, matched_pairs)
+        return native.triangulate(projs_arr, uv, damping_factor, iteration)
+
+    @staticmethod
+    def _pack_views(projs, matched_pairs):
+        num_views = len(matched_pairs)
+        num_pts = matched_pairs[0].shape[1]
+        uv = np.empty((num_views, 2, num_pts), dtype=np.float64)
+        for v in range(num_views):
+            uv[v] = np.asarray(matched_pairs[v])[0:2, :]
+        projs_arr = np.stack([np.asarray(p, dtype=np.float64).reshape(3, 4) for p in projs])
+        return uv, projs_arr
+
+    def linear_triangulate(self, projs, matched_pairs):
+        """DLT triangulation (triangulation_processor.py:91-157) on the device: per point the null
+        vector of the (2V x 4) system, divided by W.  Same sanity checks / prints / ``None`` returns."""
+        if len(matched_pairs) != len(projs) != 2:       # sic: chained comparison of the reference (Q12)
+            print('{}:{} - num of projs {} and matched pairs {} need to be 2'.format(
+                self.__class__.__name__, 'linear_triangulate', len(projs), len(matched_pairs)))
+            return None
+        if matched_pairs[0].shape[1] != matched_pairs[1].shape[1]:
+            print('{}:{} - matched pairs number does not match {} vs {}'.format(
+                self.__class__.__name__, 'linear_triangulate',
+                matched_pairs[0].shape[1], matched_pairs[1].shape[1]))
+            return None
+        uv, projs_arr = self._pack_views(projs, matched_pairs)
+        return native.tri_linear(projs_arr, uv)
 
 
 class HipTriangulationProcessor(HipTriangulationMixin):
-    """Standalone TriangulationProcessor: constructor state of triangulation_processor.py:12-28.
-
-    ``linear_triangulate`` (the DLT initialiser, tri:91-157) is host-side NumPy here: it is an
-    adjacent row of the scope table, not part of the device hot path."""
+    """Standalone TriangulationProcessor: constructor state of triangulation_processor.py:12-28."""
 
     def __init__(self, damping_factor=0.5, iteration=100):
         self.damping_factor = damping_factor
@@ -96,33 +119,6 @@ class HipTriangulationProcessor(HipTriangulationMixin):
             self.tri_pts = tri_pt
         else:
             self.tri_pts = np.hstack((self.tri_pts, tri_pt))
-
-    def linear_triangulate(self, projs, matched_pairs):
-        if len(matched_pairs) != len(projs) != 2:       # sic: chained comparison of the reference (Q12)
-            print('{}:{} - num of projs {} and matched pairs {} need to be 2'.format(
-                self.__class__.__name__, 'linear_triangulate', len(projs), len(matched_pairs)))
-            return None
-        if matched_pairs[0].shape[1] != matched_pairs[1].shape[1]:
-            print('{}:{} - matched pairs number does not match {} vs {}'.format(
-                self.__class__.__name__, 'linear_triangulate',
-                matched_pairs[0].shape[1], matched_pairs[1].shape[1]))
-            return None
-        num_views = len(matched_pairs)
-        num_pts = matched_pairs[0].shape[1]
-        a = np.zeros((num_pts, 2 * num_views, 4))
-        for v in range(num_views):
-            proj = np.asarray(projs[v], dtype=np.float64)
-            u = np.asarray(matched_pairs[v])[0, :]
-            w = np.asarray(matched_pairs[v])[1, :]
-            a[:, 2 * v, :] = u[:, None] * proj[2:3, :] - proj[0:1, :]
-            a[:, 2 * v + 1, :] = w[:, None] * proj[2:3, :] - proj[1:2, :]
-        out = np.zeros((4, num_pts))
-        out[3, :] = 1.0
-        if num_pts:
-            _, _, vh = np.linalg.svd(a)
-            x = vh[:, -1, :]
-            out[:, :] = (x / x[:, 3:4]).T
-        return out
 
 
 # ------------------------------------------------------------------------------------------------
