@@ -73,9 +73,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under torch.distributed.run (RANK set) the RCCL path is taken even with one rank, so the same code
+    # that runs on 8 GPUs can be exercised on a 1-GPU box; a plain `python bench.py` skips the process group.
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     # ---- workload: weak-scaled C3 ------------------------------------------------------------
     cfg = dict(sfm.scenes.CONFIGS[args.config])
@@ -88,17 +92,17 @@ def main():
     engine = sfm.sharding.HipShardEngine(scene.n_cams, ptr_l, cam_l, uv_l, device)
     schur_mode = {"auto": native.SCHUR_AUTO, "pairs": native.SCHUR_PAIRS, "mfma": native.SCHUR_MFMA}[args.schur]
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
-    all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if world > 1 else None
+    all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_dist else None
     ba = sfm.sharding.ShardedBa(engine, all_reduce, world)
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def gather_state():
         cams, pts_loc = engine.get_state()
-        if world == 1:
+        if not use_dist:
             return cams, pts_loc
         parts = [None] * world
         dist.all_gather_object(parts, pts_loc)
@@ -132,7 +136,7 @@ def main():
     ba.iterate(LAMBDA, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,7 +222,7 @@ def main():
 
     if world > 1 or args.no_cpu_baseline:
         engine.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -62,6 +62,9 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 template <int G, bool CAMS_IN_LDS, bool WRITE_Z>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   extern __shared__ double lds[];
+  unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
+  int sidx = 0;
+  if (stamp) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   double* lds_prep = lds;                    // V * 19
   double* lds_acc = lds + (size_t)d.V * 19;  // V * 35
   const CamPrep* gprep = d.prep[cur];
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     for (int i = threadIdx.x; i < d.V * 35; i += blockDim.x) lds_acc[i] = 0.0;
     __syncthreads();
   }
+  if (stamp) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   constexpr int GPB = 256 / G;                 // point groups per block
   const int lane_g = threadIdx.x % G;
   const int grp = threadIdx.x / G;
@@ -103,16 +107,14 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
       g3[1] += Jx[1] * r[0] + Jx[4] * r[1];
       g3[2] += Jx[2] * r[0] + Jx[5] * r[1];
     }
+    if (stamp && sidx < 60) { asm volatile("" :: "v"(v6[0])); stamp[sidx++] = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
-    for (int s = G / 2; s > 0; s >>= 1) {
+    for (int k = 0; k < 6; ++k) v6[k] = group_sum<G>(v6[k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) v6[k] += __shfl_xor(v6[k], s, G);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) g3[k] += __shfl_xor(g3[k], s, G);
-    }
+    for (int k = 0; k < 3; ++k) g3[k] = group_sum<G>(g3[k]);
     v6[0] += lambda; v6[2] += lambda; v6[5] += lambda;     // ba:359
     double li[6];
-    chol3_inv(v6, li);
+    chol3_inv_fast(v6, li);
     const double y0 = li[0] * g3[0];
     const double y1 = li[1] * g3[0] + li[2] * g3[1];
     const double y2 = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
 #pragma unroll
       for (int k = 0; k < 6; ++k) d.lip[(size_t)p * 6 + k] = li[k];      // 48 B/point for the Schur producers
     }
+    if (stamp && sidx < 60) { asm volatile("" :: "v"(y2)); stamp[sidx++] = __builtin_amdgcn_s_memtime(); }
     const bool single = (end - beg) <= G;
     for (int o = beg + lane_g; o < end; o += G) {
       if (!single) {
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
       }
     }
   }
+  if (stamp && sidx < 62) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   if (CAMS_IN_LDS) {
     // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_cam_reduce_kernel adds
     // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     double* row = d.lin_ws + (size_t)blockIdx.x * d.V * 35;
     for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) row[t] = lds_acc[t];
   }
+  if (stamp && sidx < 63) { stamp[sidx++] = __builtin_amdgcn_s_memtime(); stamp[63] = sidx; }
 }
 
 // Sum the per-workgroup camera accumulators of ba_linearize into the diagonal blocks of S (lower
@@ -240,14 +245,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev d, int cur, doubl
       a[8] += Jx[2] * e0 + Jx[5] * e1;
     }
 #pragma unroll
-    for (int s = G / 2; s > 0; s >>= 1) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) a[k] += __shfl_xor(a[k], s, G);
-    }
+    for (int k = 0; k < 9; ++k) a[k] = group_sum<G>(a[k]);
     if (lane_g == 0 && p < d.N) {
       a[0] += lambda; a[2] += lambda; a[5] += lambda;
       double li[6];
-      chol3_inv(a, li);
+      chol3_inv_fast(a, li);
       const double y0 = li[0] * a[6];
       const double y1 = li[1] * a[6] + li[2] * a[7];
       const double y2 = li[3] * a[6] + li[4] * a[7] + li[5] * a[8];
@@ -293,16 +295,6 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (the library 1.0/sqrt(d) is
-// ~50 dependent instructions and sits on the critical path of every column step).
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  r = r * (1.5 - h * r * r);
-  r = r * (1.5 - h * r * r);
-  return r;
 }
 
 // One wave: a[] = this lane's row (lanes 0..31: rows of the SPD block D, lower part valid; lanes

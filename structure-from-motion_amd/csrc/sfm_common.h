@@ -67,10 +67,55 @@ __device__ __forceinline__ void report_status(int* status, int code, int index) 
   if (code != SFM_OK && atomicCAS(&status[0], 0, code) == 0) status[1] = index;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+// Cross-lane moves on the DPP path (no LDS crossbar): quad_perm xor-1 / xor-2, row_half_mirror, row_mirror.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over aligned groups of G lanes (G = 4, 8, 16, 32, 64); every lane of the group gets the sum.
+// Up to 16 lanes stay on DPP: xor-1, xor-2 inside quads, then i <-> 7-i inside half rows, then
+// i <-> 15-i inside rows (mirrors pair each partial sum with a disjoint one, so four steps cover a row);
+// only the 32- and 64-lane steps go through ds_bpermute.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+  v += dpp_f64<0xB1>(v);                       // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);                       // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_f64<0x141>(v);          // row_half_mirror
+  if (G >= 16) v += dpp_f64<0x140>(v);         // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (sqrt / division expand to
+// ~50 dependent instructions each).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  r = r * (1.5 - h * r * r);
+  r = r * (1.5 - h * r * r);
+  return r;
+}
+
+// chol3_inv without sqrt or division: a = (a00,a10,a11,a20,a21,a22) SPD -> Li = L^-1 (lower, packed).
+__device__ __forceinline__ void chol3_inv_fast(const double* a, double* li) {
+  const double i00 = rsqrt_nr(a[0]);
+  const double l10 = a[1] * i00;
+  const double i11 = rsqrt_nr(a[2] - l10 * l10);
+  const double l20 = a[3] * i00;
+  const double l21 = (a[4] - l20 * l10) * i11;
+  const double i22 = rsqrt_nr(a[5] - l20 * l20 - l21 * l21);
+  li[0] = i00;
+  li[1] = -l10 * i00 * i11;
+  li[2] = i11;
+  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
+  li[4] = -l21 * i11 * i22;
+  li[5] = i22;
+}
+
+__device__ __forceinline__ double wave_sum(double v) { return group_sum<64>(v); }
 
 }  // namespace sfm

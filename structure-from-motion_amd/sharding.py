@@ -97,6 +97,6 @@ class ShardedBa:
         with self.engine.stream_context():
             for _ in range(iters):
                 buf = self.engine.linearize_reduce(lam, quirks)
-                if self.world_size > 1:
+                if self.all_reduce is not None:
                     self.all_reduce(buf)
                 self.engine.solve_update(lam, quirks)
