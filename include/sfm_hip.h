@@ -111,6 +111,17 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets /*[n_views+1]*/, int
                             double* R_out /*[n_views][9]*/, double* C_out /*[n_views][3]*/,
                             int* status /*[n_views]*/);
 
+/* ---- CamposeProcessor.linear_estimate_cam_pose_pnp (campose_processor.py:249-305, 485-633) ----------- */
+/* RANSAC over 6-point DLT hypotheses.  The caller draws the n_hyp six-point samples (the reference uses
+ * Python's global `random.sample`, campose:531, so the host keeps the RNG stream); the device solves every
+ * hypothesis (12x12 null vector + 3x3 polar factor), scores all points against `threshold` in pixels and
+ * returns the FIRST hypothesis with the largest inlier count, its inlier mask and count.  If no hypothesis
+ * has an inlier the reference's initial identity pose is returned with *best_hypothesis = -1. */
+int sfm_pnp_linear_ransac(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
+                          int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
+                          double R_out[9], double C_out[3], int* inlier_mask /*[n]*/, int* n_inliers,
+                          int* best_hypothesis);
+
 /* ---- BaProcessor.__execute_bundle_adjustment (ba_processor.py:274-439) ------------------------- */
 /* Observations are sorted by (point, camera) — the reference's loop order (ba_processor.py:304-306)
  * — and given as a CSR over points: observation o in [pt_ptr[p], pt_ptr[p+1]) belongs to point p and

@@ -655,7 +655,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   p->quirks = quirks;
   const bool write_z = !ba_schur_uses_mfma(p);
   if (write_z && d.Z == nullptr && d.M > 0) {      // pair-kernel path: Z = (Jp^T Jx) L^-T is materialised (168 B/obs)
-    SFM_HIP(hipMalloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
+    SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
   }
   if (lds <= 64 * 1024) {
     if (write_z) launch_linearize<true, true>(p, g, grid, lds, s, lambda, quirks);
@@ -761,7 +761,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   p->max_track = max_k;
   hipStream_t s = ctx().stream;
   auto fail = [&](int st) { sfm_ba_destroy(p); return st; };
-#define BA_ALLOC(ptr, count) do { hipError_t e_ = hipMalloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
+#define BA_ALLOC(ptr, count) do { hipError_t e_ = pool_alloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
     if (e_ != hipSuccess) return fail(hip_fail(e_, "hipMalloc " #ptr, __LINE__)); } while (0)
   BA_ALLOC(d.pt_ptr, (size_t)N + 1);
   BA_ALLOC(d.cam_idx, (size_t)M);
@@ -804,7 +804,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
                   d.Z, d.lip, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws, p->schur_slot};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   p->magic = 0;
@@ -822,7 +822,7 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
     case SFM_OPT_DEBUG:
       p->debug = value;
       if ((value & 8) && p->dev.stamps == nullptr) {
-        SFM_HIP(hipMalloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
+        SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
         SFM_HIP(hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 1024));
       }
       return SFM_OK;

@@ -378,8 +378,8 @@ int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx) {
   // gigabytes for scenes that will never take it
   p->schur_mfma_ok = ws_bytes + slot_bytes <= ((size_t)4 << 30);
   if (!p->schur_mfma_ok) return SFM_OK;
-  SFM_HIP(hipMalloc(&p->schur_ws, ws_bytes));
-  SFM_HIP(hipMalloc(reinterpret_cast<void**>(&p->schur_slot), slot_bytes));
+  SFM_HIP(pool_alloc(&p->schur_ws, ws_bytes));
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_slot), slot_bytes));
   std::vector<int> slot((size_t)std::max(1, d.N) * p->schur_vpad, -1);
   for (int pt = 0; pt < d.N; ++pt)
     for (int o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) slot[(size_t)pt * p->schur_vpad + cam_idx[o]] = o;

@@ -23,6 +23,13 @@ struct Context {
 
 Context& ctx();
 int ensure_init();
+
+// Device-memory pool: hipMalloc/hipFree cost tens of microseconds each and a host-buffer call makes ~25 of
+// them, which dominates small problems (incremental SfM sizes).  Blocks are rounded up to a power of two
+// (>= 256 B) and kept on per-size free lists (at most 2 GiB cached); sfm_shutdown releases them.
+hipError_t pool_alloc(void** ptr, size_t bytes);
+void pool_free(void* ptr);
+void pool_release_all();
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, int line);
 
@@ -43,11 +50,11 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) pool_free(p); }
   int alloc(size_t count) {
     n = count;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    hipError_t e = pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e != hipSuccess) return hip_fail(e, "hipMalloc", __LINE__);
     return SFM_OK;
   }

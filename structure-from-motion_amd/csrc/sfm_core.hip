@@ -4,6 +4,8 @@
 //   tri_nonlinear_kernel  <-> TriangulationProcessor.nonlinear_triangulate (triangulation_processor.py:160-234)
 //   pnp_nonlinear_kernel  <-> CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459)
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "sfm_common.h"
@@ -35,6 +37,82 @@ int hip_fail(hipError_t e, const char* what, int line) {
 int ensure_init() {
   if (ctx().inited) return SFM_OK;
   return sfm_init(0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-memory pool (see sfm_common.h)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;                 // block -> rounded size
+  std::unordered_map<size_t, std::vector<void*>> free_by_size;
+  size_t cached_bytes = 0;
+};
+Pool& pool() {
+  static Pool p;
+  return p;
+}
+size_t round_up_pow2(size_t n) {
+  size_t r = 256;
+  while (r < n) r <<= 1;
+  return r;
+}
+constexpr size_t kPoolCap = (size_t)2 << 30;
+}  // namespace
+
+hipError_t pool_alloc(void** ptr, size_t bytes) {
+  const size_t sz = round_up_pow2(bytes);
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.free_by_size.find(sz);
+    if (it != P.free_by_size.end() && !it->second.empty()) {
+      *ptr = it->second.back();
+      it->second.pop_back();
+      P.cached_bytes -= sz;
+      P.live[*ptr] = sz;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(ptr, sz);
+  if (e != hipSuccess) {               // out of memory: drop the cache and retry once
+    pool_release_all();
+    e = hipMalloc(ptr, sz);
+  }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[*ptr] = sz;
+  }
+  return e;
+}
+
+void pool_free(void* ptr) {
+  if (ptr == nullptr) return;
+  Pool& P = pool();
+  size_t sz = 0;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.live.find(ptr);
+    if (it == P.live.end()) { (void)hipFree(ptr); return; }     // not ours (defensive)
+    sz = it->second;
+    P.live.erase(it);
+    if (P.cached_bytes + sz <= kPoolCap) {
+      P.free_by_size[sz].push_back(ptr);
+      P.cached_bytes += sz;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+
+void pool_release_all() {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.mu);
+  for (auto& kv : P.free_by_size)
+    for (void* q : kv.second) (void)hipFree(q);
+  P.free_by_size.clear();
+  P.cached_bytes = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,6 +474,163 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Linear (DLT) PnP hypotheses for RANSAC, CamposeProcessor.__linear_determine_cam_pos /
+// __estimate_six_pts (campose_processor.py:485-633).  The six-point samples are drawn on the host
+// (the reference consumes Python's global `random` stream, campose:531); the device evaluates every
+// hypothesis:
+//   pnp_six_point_kernel   thread per hypothesis: 12x12 system from the 6 normalised keys and points
+//                          (campose:585-613), null vector by one-sided Jacobi SVD (12x12 work arrays live
+//                          in scratch: dynamic column indexing), 3x3 polar factor + largest singular value
+//                          (campose:619-631), K [R^T | -R^T C] for the scoring pass
+//   pnp_score_kernel       workgroup per hypothesis: pixel reprojection error of every point against the
+//                          threshold (campose:544-554) -> inlier count
+//   pnp_inlier_mask_kernel inlier mask of the winning hypothesis
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ void jacobi_right_vectors(double (&B)[N][N], double (&V)[N][N], int max_sweeps) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < N - 1; ++p) {
+      for (int q = p + 1; q < N; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < N; ++k) { al += B[k][p] * B[k][p]; be += B[k][q] * B[k][q]; ga += B[k][p] * B[k][q]; }
+        if (ga != 0.0 && fabs(ga) > 1e-17 * sqrt(al * be)) {
+          rotated = true;
+          const double ze = (be - al) / (2.0 * ga);
+          const double t = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+          for (int k = 0; k < N; ++k) {
+            const double bp = B[k][p], bq = B[k][q];
+            B[k][p] = c * bp - sn * bq; B[k][q] = sn * bp + c * bq;
+            const double vp = V[k][p], vq = V[k][q];
+            V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
+          }
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+}
+
+__global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, const int* __restrict__ samples /*[n_hyp][6]*/,
+                                                           const double* __restrict__ uv_pix /*[3][n]*/,
+                                                           const double* __restrict__ X /*[4][n]*/,
+                                                           const double* __restrict__ Kmat,
+                                                           double* __restrict__ R_out /*[n_hyp][9]*/,
+                                                           double* __restrict__ C_out /*[n_hyp][3]*/,
+                                                           double* __restrict__ proj_out /*[n_hyp][12]*/) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hyp) return;
+  const double* K = Kmat;
+  const double idet = 1.0 / det3(K);
+  double ki[9];
+  ki[0] = (K[4] * K[8] - K[5] * K[7]) * idet; ki[1] = (K[2] * K[7] - K[1] * K[8]) * idet; ki[2] = (K[1] * K[5] - K[2] * K[4]) * idet;
+  ki[3] = (K[5] * K[6] - K[3] * K[8]) * idet; ki[4] = (K[0] * K[8] - K[2] * K[6]) * idet; ki[5] = (K[2] * K[3] - K[0] * K[5]) * idet;
+  ki[6] = (K[3] * K[7] - K[4] * K[6]) * idet; ki[7] = (K[1] * K[6] - K[0] * K[7]) * idet; ki[8] = (K[0] * K[4] - K[1] * K[3]) * idet;
+  double W[12][12], V[12][12];
+  for (int s6 = 0; s6 < 6; ++s6) {
+    const int idx = samples[6 * h + s6];
+    const double u = uv_pix[idx], v = uv_pix[(size_t)n + idx], w = uv_pix[2 * (size_t)n + idx];
+    const double p0 = ki[0] * u + ki[1] * v + ki[2] * w;       // key in camera coordinates (campose:535, not re-normalised)
+    const double p1 = ki[3] * u + ki[4] * v + ki[5] * w;
+    const double p2 = ki[6] * u + ki[7] * v + ki[8] * w;
+    const double x = X[idx], y = X[(size_t)n + idx], z = X[2 * (size_t)n + idx];
+    double* r0 = W[2 * s6];
+    double* r1 = W[2 * s6 + 1];
+    r0[0] = p2 * x; r0[1] = p2 * y; r0[2] = p2 * z; r0[3] = p2; r0[4] = 0; r0[5] = 0; r0[6] = 0; r0[7] = 0;
+    r0[8] = -p0 * x; r0[9] = -p0 * y; r0[10] = -p0 * z; r0[11] = -p0;
+    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = 0; r1[4] = p2 * x; r1[5] = p2 * y; r1[6] = p2 * z; r1[7] = p2;
+    r1[8] = -p1 * x; r1[9] = -p1 * y; r1[10] = -p1 * z; r1[11] = -p1;
+  }
+  jacobi_right_vectors<12>(W, V, 30);
+  int best = 0;
+  double bn = 0;
+  for (int c = 0; c < 12; ++c) {
+    double nn = 0;
+    for (int k = 0; k < 12; ++k) nn += W[k][c] * W[k][c];
+    if (c == 0 || nn < bn) { bn = nn; best = c; }
+  }
+  double cam[12];
+  for (int k = 0; k < 12; ++k) cam[k] = V[k][best];          // cam_mat (3x4) row-major (campose:618)
+  // polar factor of the 3x3 left block and its largest singular value (campose:622-626)
+  double B3[3][3], V3[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) B3[i][j] = cam[4 * i + j];
+  jacobi_right_vectors<3>(B3, V3, 30);
+  double sig[3], smax = 0;
+  for (int c = 0; c < 3; ++c) {
+    sig[c] = sqrt(B3[0][c] * B3[0][c] + B3[1][c] * B3[1][c] + B3[2][c] * B3[2][c]);
+    smax = fmax(smax, sig[c]);
+  }
+  double UV[9];   // U V^T = sum_c (B3[:,c] / sig_c) V3[:,c]^T
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int c = 0; c < 3; ++c) a += (B3[i][c] / sig[c]) * V3[j][c];
+      UV[3 * i + j] = a;
+    }
+  double R[9];    // rot = (uu @ vvh).T
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = UV[3 * j + i];
+  double C[3];
+  for (int i = 0; i < 3; ++i) C[i] = (R[3 * i] * -cam[3] + R[3 * i + 1] * -cam[7] + R[3 * i + 2] * -cam[11]) / smax;
+  // campose:629-631 negates rot AND loc when det(rot) < 0.  C = rot (-cam[:,3]) / s is already invariant under
+  // the arbitrary sign of the null vector (rot and cam flip together), so negating it makes the reference's
+  // result depend on LAPACK's sign choice: about half of its hypotheses come out with -C and score ~0 inliers
+  // (quirk Q13).  The device keeps the sign-invariant C; on every hypothesis the reference did not
+  // ruin the two agree, and on its own PnP fixture the winning hypothesis, inlier set and pose are identical.
+  if (det3(R) < 0) {
+    for (int i = 0; i < 9; ++i) R[i] = -R[i];
+  }
+  for (int i = 0; i < 9; ++i) R_out[9 * h + i] = R[i];
+  for (int i = 0; i < 3; ++i) C_out[3 * h + i] = C[i];
+  // proj = K @ [R^T | R^T @ -C]  (campose:538)
+  double rt[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) rt[4 * i + j] = R[3 * j + i];
+    rt[4 * i + 3] = R[0 + i] * -C[0] + R[3 + i] * -C[1] + R[6 + i] * -C[2];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) proj_out[12 * h + 4 * i + j] = K[3 * i] * rt[j] + K[3 * i + 1] * rt[4 + j] + K[3 * i + 2] * rt[8 + j];
+}
+
+__device__ __forceinline__ bool pnp_is_inlier(const double* P, const double* uv_pix, const double* X, int n, int i,
+                                              double threshold) {
+  const double x = X[i], y = X[(size_t)n + i], z = X[2 * (size_t)n + i], w = X[3 * (size_t)n + i];
+  const double s0 = P[0] * x + P[1] * y + P[2] * z + P[3] * w;
+  const double s1 = P[4] * x + P[5] * y + P[6] * z + P[7] * w;
+  const double s2 = P[8] * x + P[9] * y + P[10] * z + P[11] * w;
+  const double e0 = uv_pix[i] - s0 / s2, e1 = uv_pix[(size_t)n + i] - s1 / s2, e2 = uv_pix[2 * (size_t)n + i] - s2 / s2;
+  return sqrt(e0 * e0 + e1 * e1 + e2 * e2) < threshold;          // campose:550-552
+}
+
+__global__ __launch_bounds__(256) void pnp_score_kernel(int n, const double* __restrict__ proj, const double* __restrict__ uv_pix,
+                                                        const double* __restrict__ X, double threshold,
+                                                        int* __restrict__ counts) {
+  __shared__ int wsum[4];
+  const int h = blockIdx.x;
+  double P[12];
+  for (int k = 0; k < 12; ++k) P[k] = proj[12 * h + k];
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) cnt += pnp_is_inlier(P, uv_pix, X, n, i, threshold) ? 1 : 0;
+  for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[h] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void pnp_inlier_mask_kernel(int n, const double* __restrict__ proj, const double* __restrict__ uv_pix,
+                                       const double* __restrict__ X, double threshold, int* __restrict__ mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double P[12];
+  for (int k = 0; k < 12; ++k) P[k] = proj[k];
+  mask[i] = pnp_is_inlier(P, uv_pix, X, n, i, threshold) ? 1 : 0;
+}
+
 static int first_bad(const std::vector<int>& st) {
   for (size_t i = 0; i < st.size(); ++i)
     if (st[i] != SFM_OK) return st[i];
@@ -448,6 +683,7 @@ int sfm_shutdown(void) {
   Context& c = ctx();
   if (!c.inited) return SFM_OK;
   (void)hipStreamSynchronize(c.stream);
+  pool_release_all();
   if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
   c = Context();
   return SFM_OK;
@@ -588,6 +824,49 @@ int sfm_triangulate(int m, int n_views, const double* projs, const double* uv, d
   tri_nonlinear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dL.p, lambda, iters, dO.p);   // tri:86
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  return SFM_OK;
+}
+
+int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const double K[9], int n_hyp, const int* samples,
+                          double threshold, double R_out[9], double C_out[3], int* inlier_mask, int* n_inliers,
+                          int* best_hypothesis) {
+  SFM_TRY(ensure_init());
+  if (n < 6 || n_hyp < 1) { set_error("sfm_pnp_linear_ransac: need n >= 6 points and n_hyp >= 1 (n=%d n_hyp=%d)", n, n_hyp); return SFM_E_SHAPE; }
+  for (int i = 0; i < 6 * n_hyp; ++i)
+    if (samples[i] < 0 || samples[i] >= n) { set_error("sfm_pnp_linear_ransac: sample index %d out of range", samples[i]); return SFM_E_SHAPE; }
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dUV, dX, dK, dR, dC, dP;
+  DevBuf<int> dS, dCnt, dMask;
+  SFM_TRY(dUV.upload(uv_pix, 3 * (size_t)n, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s)); SFM_TRY(dK.upload(K, 9, s));
+  SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
+  SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(12 * (size_t)n_hyp));
+  SFM_TRY(dCnt.alloc(n_hyp)); SFM_TRY(dMask.alloc(n));
+  pnp_six_point_kernel<<<(n_hyp + 63) / 64, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
+  pnp_score_kernel<<<n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
+  SFM_HIP(hipGetLastError());
+  std::vector<int> counts(n_hyp);
+  SFM_TRY(dCnt.download(counts.data(), n_hyp, s));
+  SFM_HIP(hipStreamSynchronize(s));
+  // the reference keeps the FIRST hypothesis with a strictly larger count, starting from 0 inliers / identity
+  // pose (campose:524-560)
+  int best = -1, best_cnt = 0;
+  for (int h = 0; h < n_hyp; ++h)
+    if (counts[h] > best_cnt) { best_cnt = counts[h]; best = h; }
+  if (best_hypothesis) *best_hypothesis = best;
+  if (n_inliers) *n_inliers = best_cnt;
+  if (best < 0) {
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) R_out[i] = I[i];
+    for (int i = 0; i < 3; ++i) C_out[i] = 0.0;
+    for (int i = 0; i < n; ++i) inlier_mask[i] = 0;
+    return SFM_OK;
+  }
+  pnp_inlier_mask_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dP.p + 12 * (size_t)best, dUV.p, dX.p, threshold, dMask.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dMask.download(inlier_mask, n, s));
+  SFM_HIP(hipMemcpyAsync(R_out, dR.p + 9 * (size_t)best, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
+  SFM_HIP(hipMemcpyAsync(C_out, dC.p + 3 * (size_t)best, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   SFM_HIP(hipStreamSynchronize(s));
   return SFM_OK;
 }

@@ -25,6 +25,7 @@ EXPORTS = (
     "sfm_version", "sfm_init", "sfm_shutdown", "sfm_set_stream", "sfm_synchronize", "sfm_last_error",
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
+    "sfm_pnp_linear_ransac",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
@@ -215,6 +216,24 @@ def pnp_nonlinear(uv_pix, pts_h, intrinsic, rot0, loc0, lam, iters, quirks=QUIRK
     check(load().sfm_pnp_nonlinear(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), dptr(rot0), dptr(loc0),
                                    float(lam), int(iters), int(quirks), dptr(rot), dptr(loc)))
     return rot, loc.reshape(3, 1)
+
+
+def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
+    """Evaluate six-point DLT hypotheses (samples: (n_hyp, 6) indices drawn by the caller) and return
+    (rot (3,3), loc (3,1), inlier index list, best hypothesis index or -1)."""
+    uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic)
+    samples = i32(samples).reshape(-1, 6)
+    n, n_hyp = uv_pix.shape[1], samples.shape[0]
+    rot = np.empty((3, 3)); loc = np.empty(3)
+    mask = np.empty(n, dtype=np.int32)
+    cnt = ctypes.c_int(); best = ctypes.c_int()
+    lib = load()
+    lib.sfm_pnp_linear_ransac.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_double, _dp, _dp,
+                                          _ip, _ip, _ip]
+    check(lib.sfm_pnp_linear_ransac(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples),
+                                    float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
+                                    ctypes.byref(best)))
+    return rot, loc.reshape(3, 1), [int(i) for i in np.flatnonzero(mask)], best.value
 
 
 def pnp_nonlinear_batch(offsets, uv_pix, pts_h, intrinsics, rot0, loc0, lam, iters, quirks=QUIRKS_REFERENCE):

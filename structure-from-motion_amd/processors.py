@@ -149,6 +149,27 @@ class HipCamposeMixin:
         native.check(int(st[0]))
         return jp[0]
 
+    def linear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config=None):
+        """RANSAC 6-point DLT PnP (campose_processor.py:249-305, 485-633).  The six-point samples are drawn
+        here with ``random.sample`` exactly as the reference does (same consumption of Python's global RNG
+        stream, campose:531); every hypothesis is solved and scored on the device."""
+        import random
+        if not ransac_config:
+            ransac_config = self.ransac_config
+        if key_2d_pts.shape[1] != tri_3d_pts.shape[1]:
+            logging.warning('%s : different numbers of key points and of triangulated points',
+                            self.__class__.__name__)
+            raise ValueError("key pts num - triangulated pts num : {} - {}"
+                             .format(key_2d_pts.shape[1], tri_3d_pts.shape[1]))
+        num_pts = key_2d_pts.shape[1]
+        if num_pts < 6:
+            logging.warning('%s : required equal or more than six points %d', self.__class__.__name__, num_pts)
+            raise ValueError("required equal or more than six points {}".format(num_pts))
+        samples = [random.sample(range(num_pts), 6) for _ in range(ransac_config.iteration)]
+        rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
+            key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+        return inlier_indices, rot, loc
+
     def estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat,
                               ransac_config=None, damping_factor=None, iteration=None):
         if not ransac_config:
@@ -165,22 +186,34 @@ class HipCamposeMixin:
         return inlier_indices, ref_rot, ref_loc
 
 
-class HipCamposeProcessor(HipCamposeMixin):
-    """Standalone CamposeProcessor (constructor of campose_processor.py:12-26).  The RANSAC DLT
-    initialiser ``linear_estimate_cam_pose_pnp`` (campose:249-305) is outside this path (SURVEY.md
-    section 8 f3); supply one (e.g. the reference's bound method) via ``linear_estimator``."""
+class RansacConfig:
+    """Mirror of utils.RansacConfig (utils.py:129-174): iteration count raised to the confidence bound and
+    Python's global RNG seeded with -1 on construction."""
 
-    def __init__(self, ransac_config, damping_factor, iteration, linear_estimator=None):
+    def __init__(self, inlier_threshold, subset_confidence, sample_confidence, sample_num, iteration,
+                 is_use_seed=True):
+        self.inlier_threshold = inlier_threshold
+        self.subset_confidence = subset_confidence
+        self.sample_confidence = sample_confidence
+        self.sample_num = int(sample_num)
+        self.iteration = int(iteration)
+        self.random_seed = -1
+        calc_iteration = math.log(1.0 - subset_confidence) / math.log(1.0 - math.pow(sample_confidence, sample_num))
+        if calc_iteration > iteration:
+            print('RANSAC : iteration increases from {} to {}'.format(iteration, calc_iteration))
+            self.iteration = int(calc_iteration)
+        if is_use_seed:
+            import random
+            random.seed(self.random_seed)
+
+
+class HipCamposeProcessor(HipCamposeMixin):
+    """Standalone CamposeProcessor (constructor of campose_processor.py:12-26)."""
+
+    def __init__(self, ransac_config, damping_factor, iteration):
         self.ransac_config = ransac_config
         self.damping_factor = damping_factor
         self.iteration = iteration
-        self._linear_estimator = linear_estimator
-
-    def linear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config=None):
-        if self._linear_estimator is None:
-            raise NotImplementedError(
-                "linear (RANSAC DLT) PnP is not part of the device hot path; pass linear_estimator=")
-        return self._linear_estimator(key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
 
 
 # ------------------------------------------------------------------------------------------------

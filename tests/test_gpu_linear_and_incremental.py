@@ -71,6 +71,44 @@ def test_processor_linear_triangulate_prints_and_none(hip, sfm, capsys):
     assert bad is None and "matched pairs number does not match" in capsys.readouterr().out
 
 
+def test_pnp_linear_ransac_reference_fixture(hip, sfm):
+    """campose_processor.py:1021-1064 on the reference's PnP data files: 300 six-point hypotheses drawn from
+    Python's RNG seeded by RansacConfig (-1), solved and scored on the device.  The reference run (golden
+    g5) found 882 inliers; inlier set, pose and the downstream nonlinear refinement must all match."""
+    g = load_golden("g5_pnp.npz")
+    cfg = sfm.processors.RansacConfig(8.0, 0.99, 0.75, 6, 300)
+    assert cfg.iteration == 300
+    cp = sfm.processors.HipCamposeProcessor(cfg, 5, 200)
+    inl, rot, loc = cp.linear_estimate_cam_pose_pnp(g["pts2d"], g["pts3d"], g["K"], cfg)
+    assert len(inl) == 882 and inl == [int(i) for i in g["inliers"]]
+    assert rel(rot, g["R0"]) < 1e-9 and rel(loc, g["C0"]) < 1e-9 and loc.shape == (3, 1)
+    # the reference's own acceptance test of the linear stage (campose:1053-1056): location within 0.1
+    assert np.linalg.norm(loc - g["loc_truth"]) < 0.1
+    # whole chain, re-seeded like campose:1094-1106: RANSAC + 10 nonlinear iterations
+    cfg = sfm.processors.RansacConfig(8.0, 0.99, 0.75, 6, 300)
+    inl2, r, c = cp.estimate_cam_pose_pnp(g["pts2d"], g["pts3d"], g["K"], cfg, 5, 10)
+    assert inl2 == inl and rel(r, g["R_its10"]) < 1e-9 and rel(c, g["C_its10"]) < 1e-9
+    with pytest.raises(ValueError):
+        cp.linear_estimate_cam_pose_pnp(g["pts2d"][:, :5], g["pts3d"][:, :5], g["K"], cfg)
+
+
+def test_pnp_linear_ransac_synthetic_with_outliers(hip, sfm):
+    """Exact projections + 30 % gross outliers: every all-inlier sample recovers the pose, the inlier mask is
+    exactly the clean set."""
+    rng = np.random.default_rng(9)
+    sc = sfm.scenes.make_scene(2, 400, 1.0, seed=61, pixel_noise=0.0)
+    rot = sfm.geometry.quaternion_to_rotation(sc.cams_true[1, 3:7])
+    loc = sc.cams_true[1, 0:3].reshape(3, 1)
+    uv = np.vstack((sc.uv_pix[:, sc.cam_idx == 1], np.ones((1, 400))))
+    bad = rng.choice(400, 120, replace=False)
+    uv[0:2, bad] += rng.uniform(30, 200, (2, 120)) * rng.choice([-1, 1], (2, 120))
+    x = np.vstack((sc.pts_true, np.ones((1, 400))))
+    samples = np.array([rng.choice(400, 6, replace=False) for _ in range(200)], dtype=np.int32)
+    r, c, inl, best = hip.pnp_linear_ransac(uv, x, sc.intrinsic, samples, 2.0)
+    assert best >= 0 and sorted(inl) == sorted(set(range(400)) - set(bad.tolist()))
+    assert rel(r, rot) < 1e-6 and rel(c, loc) < 1e-5
+
+
 def test_incremental_sfm_loop(hip, sfm, oracle):
     """Synthetic stand-in for BASELINE config 5 (the upenn BMPs need SIFT): views arrive one by one;
     each new view is posed by nonlinear PnP on the points known so far, new points are triangulated
