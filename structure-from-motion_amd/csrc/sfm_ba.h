@@ -52,6 +52,7 @@ struct sfm_ba_problem {
   sfm::BaDev dev;
   int cur = 0;               // which prep slot holds the cameras of the current state
   bool prep_valid = false;
+  bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
   int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight (the Schur producers re-derive it)

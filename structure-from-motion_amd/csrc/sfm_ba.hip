@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev d, int cur, doubl
   constexpr int GPB = 256 / G;
   const int lane_g = threadIdx.x % G;
   const int grp = threadIdx.x / G;
+  // [S | rhs] is dead once ba_back_solve has run: clear it here (a few hundred bytes per workgroup) so the
+  // next iteration's linearisation needs no separate memset
+  {
+    const size_t n_red = (size_t)d.ld * d.ld + d.ld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_red; i += (size_t)gridDim.x * blockDim.x) d.red[i] = 0.0;
+  }
   for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
     const int p = p0 + grp;
     int beg = 0, end = 0;
@@ -645,7 +651,8 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = ctx().stream;
   const BaDev& d = p->dev;
   if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
-  SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
+  if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
+  p->red_clean = false;
   const int g = pick_group(p);
   const int gpb = 256 / g;
   int grid = std::min((d.N + gpb - 1) / gpb, kLinGridPerCu * ctx().num_cus);
@@ -702,6 +709,7 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   else launch_backsub<false>(p, g, grid, 0, s, lambda, quirks);
   tick(p, SFM_K_BACKSUB, false, s);
   SFM_HIP(hipGetLastError());
+  p->red_clean = true;      // ba_backsub_kernel cleared [S | rhs]
   p->cur ^= 1;      // ba_back_solve_kernel prepared the updated cameras into the other slot
   return SFM_OK;
 }
@@ -903,6 +911,7 @@ int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubl
 int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
   SFM_TRY(check_problem(p));
   const int64_t need = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  p->red_clean = false;
   if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
   if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }
   p->dev.red = static_cast<double*>(device_ptr);

@@ -351,17 +351,23 @@ static SchurPlan make_plan(const BaDev& d) {
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
   const int slabs = std::max(1, (d.N + SP - 1) / SP);
-  // target ~2 workgroups per CU in total, chunks_diag : chunks_off = 9 : 16
-  const double target = 2.0 * ctx().num_cus;
-  const double a = target / (pl.n_off + (9.0 / 16.0) * pl.nblk);
+  // ONE workgroup per CU in total (each needs 116 KB of LDS, so a CU hosts one at a time): a single even
+  // round pays the per-workgroup setup / prologue / slab write once and halves the split-K slab traffic
+  // compared with two rounds.  chunks_diag : chunks_off = 9 : 16; shrink until everything fits one round.
   auto fit = [&](double want, int& chunks, int& ppc) {
     int c = std::max(1, std::min(slabs, (int)(want + 0.5)));
     const int slabs_per = (slabs + c - 1) / c;
     ppc = slabs_per * SP;
     chunks = (slabs + slabs_per - 1) / slabs_per;
   };
-  fit(a, pl.chunks_off, pl.ppc_off);
-  fit(a * 9.0 / 16.0, pl.chunks_diag, pl.ppc_diag);
+  double target = (double)ctx().num_cus;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    const double a = target / (pl.n_off + (9.0 / 16.0) * pl.nblk);
+    fit(a, pl.chunks_off, pl.ppc_off);
+    fit(a * 9.0 / 16.0, pl.chunks_diag, pl.ppc_diag);
+    if (pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag <= ctx().num_cus || target < 8) break;
+    target -= 1.0;
+  }
   if (pl.n_off == 0) { pl.chunks_off = 0; pl.ppc_off = SP; }
   return pl;
 }

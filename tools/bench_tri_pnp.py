@@ -71,6 +71,30 @@ def main():
                                                     np.stack([g["C0"][:, 0]] * nv), 5, 200), reps=3)
     out["pnp_batch_256views_1000pts_200its"] = {"gpu_s_incl_pcie": t_gpu, "views_per_s": nv / t_gpu,
                                                 "point_iterations_per_s": nv * n * 200 / t_gpu}
+    # linear PnP RANSAC on the reference's fixture (300 hypotheses x 1639 points)
+    import random
+    random.seed(-1)
+    samples = [random.sample(range(g["pts2d"].shape[1]), 6) for _ in range(300)]
+    t_gpu = best(lambda: native.pnp_linear_ransac(g["pts2d"], g["pts3d"], g["K"], samples, 8.0))
+    out["pnp_linear_ransac_300hyp_1639pts"] = {"gpu_s": t_gpu, "reference_python_s": 3.5}
+
+    # DLT triangulation, 1538 pairs (reference: 0.05 s) and 1M points x 3 views
+    g4 = np.load(os.path.join(REPO, "tests", "golden", "g4_tri.npz"))
+    uv4 = np.ascontiguousarray(g4["cv_uv"][:, 0:2, :])
+    out["tri_linear_1538pts"] = {"gpu_s": best(lambda: native.tri_linear(g4["cv_projs"], uv4)), "reference_python_s": 0.05}
+    out["tri_linear_1Mpts_3views"] = {"gpu_s_incl_pcie": best(lambda: native.tri_linear(np.stack(projs), uvs), reps=3)}
+
+    # small-scene BA (the size of the reference's stored demo result: 6 views x 1260 points), host-buffer path
+    scs = sfm.scenes.make_scene(6, 1260, 0.7, seed=2)
+    uvn = sfm.geometry.normalise_pixels(scs.uv_pix, scs.intrinsic)
+    t_call = best(lambda: native.ba_solve(scs.n_cams, scs.pt_ptr, scs.cam_idx, uvn, scs.cams_init, scs.pts_init, 5.0, 3))
+    with native.BaProblem(scs.n_cams, scs.pt_ptr, scs.cam_idx, uvn) as prob:
+        prob.set_state(scs.cams_init, scs.pts_init)
+        def run():
+            prob.iterate(5.0, 30)
+            native.synchronize()
+        t_res = best(run) / 30
+    out["ba_small_6x1260"] = {"ba_solve_3its_incl_setup_s": t_call, "resident_s_per_iteration": t_res}
     print(json.dumps(out))
 
 
