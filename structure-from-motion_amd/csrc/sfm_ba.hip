@@ -57,20 +57,24 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 
 // ---------------------------------------------------------------------------------------------
 // ba_linearize: G lanes per point (G = power of two <= 64 chosen from the mean track length).
-// LDS: [V][19] prepared cameras + [V][35] camera-side accumulators when they fit (CAMS_IN_LDS).
+// LDS_MODE 2: [V][19] prepared cameras + [V][35] camera-side accumulators in LDS (V <= 151);
+// LDS_MODE 1: accumulators only, cameras read from global/L2 (V <= 234); LDS_MODE 0: global atomics.
 // ---------------------------------------------------------------------------------------------
-template <int G, bool CAMS_IN_LDS, bool WRITE_Z>
+template <int G, int LDS_MODE, bool WRITE_Z>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
   int sidx = 0;
   if (stamp) stamp[sidx++] = __builtin_amdgcn_s_memtime();
-  double* lds_prep = lds;                    // V * 19
-  double* lds_acc = lds + (size_t)d.V * 19;  // V * 35
+  constexpr bool PREP_LDS = LDS_MODE == 2, ACC_LDS = LDS_MODE >= 1;
+  double* lds_prep = lds;                                        // V * 19 (mode 2)
+  double* lds_acc = lds + (PREP_LDS ? (size_t)d.V * 19 : 0);     // V * 35
   const CamPrep* gprep = d.prep[cur];
-  if (CAMS_IN_LDS) {
-    const double* src = reinterpret_cast<const double*>(gprep);
-    for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_prep[i] = src[i];
+  if (ACC_LDS) {
+    if (PREP_LDS) {
+      const double* src = reinterpret_cast<const double*>(gprep);
+      for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_prep[i] = src[i];
+    }
     for (int i = threadIdx.x; i < d.V * 35; i += blockDim.x) lds_acc[i] = 0.0;
     __syncthreads();
   }
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     for (int o = beg + lane_g; o < end; o += G) {
       cam = d.cam_idx[o];
       CamPrep c;
-      load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
+      load_cam(c, PREP_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
       obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
       v6[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
       v6[1] += Jx[1] * Jx[0] + Jx[4] * Jx[3];
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
       if (!single) {
         cam = d.cam_idx[o];
         CamPrep c;
-        load_cam(c, CAMS_IN_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
+        load_cam(c, PREP_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
         obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
       }
       double* zo = WRITE_Z ? d.Z + o : nullptr;   // SoA: element e of observation o at Z[e * M + o]
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
         acc[28 + i] = Jp[i] * r[0] + Jp[7 + i] * r[1] - (z0 * y0 + z1 * y1 + z2 * y2);
       }
-      if (CAMS_IN_LDS) {
+      if (ACC_LDS) {
         double* a = lds_acc + (size_t)cam * 35;
 #pragma unroll
         for (int q = 0; q < 35; ++q) atomicAdd(a + q, acc[q]);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     }
   }
   if (stamp && sidx < 62) stamp[sidx++] = __builtin_amdgcn_s_memtime();
-  if (CAMS_IN_LDS) {
+  if (ACC_LDS) {
     // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_cam_reduce_kernel adds
     // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
     // addresses: ~18 G atomics/s on MI355X, 50 us at C3.)
@@ -596,7 +600,7 @@ static int pick_group(const sfm_ba_problem* p) {
   return g;
 }
 
-template <bool LDS, bool WZ>
+template <int LDS, bool WZ>
 static void launch_linearize(const sfm_ba_problem* p, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
   const BaDev& d = p->dev;
   switch (g) {
@@ -664,14 +668,19 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   if (write_z && d.Z == nullptr && d.M > 0) {      // pair-kernel path: Z = (Jp^T Jx) L^-T is materialised (168 B/obs)
     SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
   }
-  if (lds <= 64 * 1024) {
-    if (write_z) launch_linearize<true, true>(p, g, grid, lds, s, lambda, quirks);
-    else launch_linearize<true, false>(p, g, grid, lds, s, lambda, quirks);
+  const size_t lds_acc = sizeof(double) * (size_t)d.V * 35;
+  const int mode = lds <= 64 * 1024 ? 2 : (lds_acc <= 64 * 1024 ? 1 : 0);
+  if (mode == 2) {
+    if (write_z) launch_linearize<2, true>(p, g, grid, lds, s, lambda, quirks);
+    else launch_linearize<2, false>(p, g, grid, lds, s, lambda, quirks);
+  } else if (mode == 1) {
+    if (write_z) launch_linearize<1, true>(p, g, grid, lds_acc, s, lambda, quirks);
+    else launch_linearize<1, false>(p, g, grid, lds_acc, s, lambda, quirks);
   } else {
-    if (write_z) launch_linearize<false, true>(p, g, grid, 0, s, lambda, quirks);
-    else launch_linearize<false, false>(p, g, grid, 0, s, lambda, quirks);
+    if (write_z) launch_linearize<0, true>(p, g, grid, 0, s, lambda, quirks);
+    else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
   }
-  if (lds <= 64 * 1024) {
+  if (mode >= 1) {
     dim3 rgrid((d.V * 35 + 255) / 256, 48);
     ba_cam_reduce_kernel<<<rgrid, 256, 0, s>>>(d, grid);
   }
@@ -780,7 +789,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
   BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
   BA_ALLOC(d.lip, (size_t)N * 6);
-  BA_ALLOC(d.lin_ws, (sizeof(double) * V * (19 + 35) <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
+  BA_ALLOC(d.lin_ws, (sizeof(double) * V * 35 <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);

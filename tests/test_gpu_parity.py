@@ -370,12 +370,14 @@ def test_processors_drop_in(hip, sfm, oracle, capsys):
 
 
 # ---- paths the headline config does not touch --------------------------------------------------------
+@pytest.mark.parametrize("n_cams", [160, 240])
 @pytest.mark.parametrize("mode", ["pairs", "mfma"])
-def test_ba_many_cameras_global_accumulator_path(hip, oracle, sfm, mode):
-    """160 cameras: the per-camera accumulators no longer fit the 64 KB LDS budget of ba_linearize /
-    ba_backsub (global-atomic path), the MFMA product has 9 camera blocks (45 tiles) and tracks are
-    short and ragged (8 % visibility)."""
-    sc = sfm.scenes.make_scene(160, 600, 0.08, seed=31)
+def test_ba_many_cameras_global_accumulator_path(hip, oracle, sfm, mode, n_cams):
+    """160 cameras: cameras + accumulators exceed the 64 KB LDS budget of ba_linearize, so only the
+    accumulators stay in LDS (mode 1) and ba_backsub reads cameras from global memory; 240 cameras: not
+    even the accumulators fit (global-atomic mode 0).  The MFMA product has 9 / 14 camera blocks and tracks
+    are short and ragged (8 % visibility)."""
+    sc = sfm.scenes.make_scene(n_cams, 600, 0.08, seed=31)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
         prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
