@@ -346,28 +346,111 @@ __device__ __forceinline__ double chol_trsm_rows(double (&a)[NB], double (*colbu
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int LP = NB + 2;   // LDS pitch 34 doubles: the (row, k) operand reads of v_mfma_f64_16x16x4 hit 32 distinct bank pairs
 
-__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
-  __shared__ double La[NB][LP];   // L[r][j-1]
-  __shared__ double Lb[NB][LP];   // L[c][j-1]
-  __shared__ double Lj[NB][LP];   // L[j][j-1] (column-j blocks with r != j)
-  __shared__ double Tm[NB][NB + 1];
-  __shared__ double Dm[NB][NB + 1];
-  __shared__ double colbuf[NB][64];   // one row per column of the elimination (written once, read once)
+// Trailing role of a column step: a 64x64 super-tile (2x2 blocks, one block per wave) of the blocks right of
+// column j gets the previous panel's update A[r][c] -= L[r][j-1] L[c][j-1]^T on the matrix pipe.  Four times
+// fewer workgroups than one per block and each L tile is loaded once for two blocks, which is what matters
+// when 7V is in the thousands (V = 200: ~1000 blocks per step).
+__device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, int sr, int sc, double (*La2)[LP],
+                                                        double (*Lb2)[LP]) {
   const int P = d.P, ld = d.ld;
   const int nbk = (P + NB - 1) / NB;
-  const int c = j + blockIdx.x, r = j + blockIdx.y;
-  if (r < c) return;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)ld * ld;
+  const int k0 = (j - 1) * NB;
+  const int rbase = j + 1 + 2 * sr, cbase = j + 1 + 2 * sc;       // block indices of the super-tile's corner
+  const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int br = wave >> 1, bc = wave & 1;
+  const int r = rbase + br, c = cbase + bc;
+  const bool valid = c <= nbk - 1 && r >= c && r <= nbk;
+  const bool is_rhs = r == nbk;
+  const int lr = lane & 15, lk = lane >> 4;
+  // old block values in the MFMA C/D layout (issued before the LDS hand-over so they overlap it)
+  double old[2][2][4];
+  if (valid) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int i = 16 * sx + lk + 4 * g;
+          const double* pr = is_rhs ? rhs : S + (size_t)(r * NB + i) * ld;
+          old[sx][sy][g] = pr[c * NB + 16 * sy + lr];
+        }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = ti + 8 * e;                 // 0..63: two stacked blocks
+    const int rb = rbase + (i >> 5), cb = cbase + (i >> 5), ii = i & 31;
+    const double* pa = rb == nbk ? rhs : S + (size_t)(min(rb, nbk - 1) * NB + ii) * ld;
+    const double va = pa[k0 + tj];
+    La2[i][tj] = (rb < nbk || (rb == nbk && ii == 0)) ? va : 0.0;
+    const double vb = S[(size_t)(min(cb, nbk - 1) * NB + ii) * ld + k0 + tj];
+    Lb2[i][tj] = cb <= nbk - 1 ? vb : 0.0;
+  }
+  __syncthreads();
+  if (!valid) return;
+  chol_f64x4 acc[2][2];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = chol_f64x4{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double a0 = La2[32 * br + lr][kk + lk], a1 = La2[32 * br + 16 + lr][kk + lk];
+    const double b0 = Lb2[32 * bc + lr][kk + lk], b1 = Lb2[32 * bc + 16 + lr][kk + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = 16 * sx + lk + 4 * g, col = c * NB + 16 * sy + lr;
+        const bool row_ok = is_rhs ? (i == 0) : (r * NB + i < P);
+        if (row_ok && col < P) (is_rhs ? rhs : S + (size_t)(r * NB + i) * ld)[col] = old[sx][sy][g] - acc[sx][sy][g];
+      }
+}
+
+__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
+  // one LDS arena, carved per role
+  constexpr int kTile = NB * LP, kSq = NB * (NB + 1);
+  __shared__ double arena[3 * kTile + 2 * kSq + NB * 64];
+  const int P = d.P, ld = d.ld;
+  const int nbk = (P + NB - 1) / NB;
+  // workgroups 0 .. nbk-j are the column role (block rows j .. nbk, the last one being the rhs row); the rest
+  // are trailing super-tiles (sr >= sc) with two 64 x 34 operand tiles
+  const int ncol = nbk - j + 1;
+  if ((int)blockIdx.x >= ncol) {
+    int t = blockIdx.x - ncol, sr = 0;
+    while (t > sr) { t -= sr + 1; ++sr; }
+    static_assert(4 * kTile <= 3 * kTile + 2 * kSq + NB * 64, "trailing tiles must fit the arena");
+    chol_trailing_supertile(d, j, sr, t, reinterpret_cast<double(*)[LP]>(arena),
+                            reinterpret_cast<double(*)[LP]>(arena + 2 * kTile));
+    return;
+  }
+  double(*La)[LP] = reinterpret_cast<double(*)[LP]>(arena);                  // L[r][j-1]
+  double(*Lb)[LP] = reinterpret_cast<double(*)[LP]>(arena + kTile);          // L[c][j-1]
+  double(*Lj)[LP] = reinterpret_cast<double(*)[LP]>(arena + 2 * kTile);      // L[j][j-1] (blocks with r != j)
+  double(*Tm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + 3 * kTile);
+  double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + 3 * kTile + kSq);
+  double(*colbuf)[64] = reinterpret_cast<double(*)[64]>(arena + 3 * kTile + 2 * kSq);   // one row per elimination column
+  const int c = j, r = j + blockIdx.x;
   const bool is_rhs = r == nbk;
   // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
-  unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
+  unsigned long long* stamp = (d.stamps && blockIdx.x == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
   double* S = d.red;
   double* rhs = d.red + (size_t)ld * ld;
   const int r0 = r * NB, c0 = c * NB, j0 = j * NB, k0 = (j - 1) * NB;
   const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
   const int lane = tid & 63, wave = tid >> 6;
-  const bool col_j = c == j;
-  const bool need_d = col_j && r != j;
+  const bool need_d = r != j;
 
   // This wave's 16x16 part of the 32x32 block, in the C/D layout of v_mfma_f64_16x16x4_f64:
   // element reg of lane l is (row = 16 sx + (l >> 4) + 4 reg, col = 16 sy + (l & 15)).
@@ -427,10 +510,6 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
     const int i = 16 * sx + lk + 4 * g;
     const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
     double t = (row_ok && col_ok) ? aT[g] : 0.0;
-    if (!col_j) {
-      if (row_ok && col_ok) (is_rhs ? rhs : S + (size_t)(r0 + i) * ld)[c0 + ocol] = t;
-      continue;
-    }
     if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
       if (i == ocol) t = col_ok ? t + lambda : 1.0;
       Dm[i][ocol] = t;
@@ -442,7 +521,6 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       Dm[i][ocol] = dv;
     }
   }
-  if (!col_j) return;
   if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
   if (tid >= 64) return;
@@ -481,7 +559,23 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 // (static register indexing; the next block's column is prefetched while all threads fold x_b into
 // the y of the blocks above, 32 independent coalesced loads per thread).  Then the camera update of
 // ba:383-392 and the preparation of the next iteration.
+// Rows beyond the 384 that ba_back_solve's update waves hold in registers; only the BIG instantiation
+// (7V > 416) contains it, so the small-system kernel keeps its register allocation.
 template <bool Y_LDS>
+__device__ __forceinline__ void back_solve_far_rows(const double* __restrict__ S, int ld, int c0, int utid,
+                                                              const double* xb, double* y) {
+  for (int i = utid + 384; i < c0; i += 192) {
+    double w[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) w[k] = S[(size_t)(c0 + k) * ld + i];
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) s += w[k] * xb[k];
+    y[i] -= s;
+  }
+}
+
+template <bool Y_LDS, bool BIG>
 __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
   extern __shared__ double ylds[];     // [ld] working copy of y when it fits (Y_LDS)
   __shared__ double xb[NB];
@@ -555,12 +649,7 @@ __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
           yref(i) -= s;
         }
       }
-      for (int i = utid + 384; i < c0; i += 192) {     // more than 384 rows above: plain loop
-        double s = 0;
-#pragma unroll 8
-        for (int k = 0; k < NB; ++k) s += S[(size_t)(c0 + k) * ld + i] * xb[k];
-        yref(i) -= s;
-      }
+      if (BIG) back_solve_far_rows<Y_LDS>(S, ld, c0, utid, xb, Y_LDS ? ylds : yg);
     }
     __syncthreads();
     if (stamp) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
@@ -698,13 +787,21 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   tick(p, SFM_K_SOLVE, true, s);
   const int nbk = (d.P + NB - 1) / NB;
   for (int j = 0; j < nbk; ++j) {
-    dim3 grid(nbk - j, nbk - j + 1);            // (block column c - j, block row r - j); row nbk = the rhs
-    ba_chol_step_kernel<<<grid, 256, 0, s>>>(d, j, lambda);
+    const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
+    // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
+    // j+1 .. nbk-1, lower part only
+    const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
+    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2, 256, 0, s>>>(d, j, lambda);
   }
   {
     const size_t ybytes = sizeof(double) * (size_t)d.ld;
-    if (ybytes <= 48 * 1024) ba_back_solve_kernel<true><<<1, 256, ybytes, s>>>(d, p->cur);
-    else ba_back_solve_kernel<false><<<1, 256, 0, s>>>(d, p->cur);
+    const bool big = d.P > 416;      // more rows above a block than the update waves hold in registers
+    if (ybytes <= 48 * 1024) {
+      if (big) ba_back_solve_kernel<true, true><<<1, 256, ybytes, s>>>(d, p->cur);
+      else ba_back_solve_kernel<true, false><<<1, 256, ybytes, s>>>(d, p->cur);
+    } else {
+      ba_back_solve_kernel<false, true><<<1, 256, 0, s>>>(d, p->cur);
+    }
   }
   tick(p, SFM_K_SOLVE, false, s);
   SFM_HIP(hipGetLastError());
