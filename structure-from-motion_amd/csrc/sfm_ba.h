@@ -38,6 +38,27 @@ struct BaDev {
   unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };
 
+// Slice `slice` of `nslices` of the sum over ba_linearize's per-workgroup camera accumulators (lin_ws rows)
+// for accumulator element t, added into the diagonal blocks of S (lower part) / rhs with one f64 atomic.
+__device__ __forceinline__ void cam_reduce_slice(const BaDev& d, int nrows, int t, int slice, int nslices) {
+  if (t >= d.V * 35) return;
+  const int per = (nrows + nslices - 1) / nslices;
+  const int r0 = slice * per, r1 = min(nrows, r0 + per);
+  double s = 0;
+  for (int r = r0; r < r1; ++r) s += d.lin_ws[(size_t)r * d.V * 35 + t];
+  if (s == 0.0) return;
+  const int c = t / 35, e = t % 35;
+  double* S = d.red;
+  double* rhs = d.red + (size_t)d.ld * d.ld;
+  if (e >= 28) {
+    atomicAdd(&rhs[7 * c + (e - 28)], s);
+  } else {
+    int i = 0, base = 0;                   // e = i(i+1)/2 + j
+    while (base + i + 1 <= e) { base += i + 1; ++i; }
+    atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + (e - base)], s);
+  }
+}
+
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int used = 0;
@@ -52,6 +73,7 @@ struct sfm_ba_problem {
   sfm::BaDev dev;
   int cur = 0;               // which prep slot holds the cameras of the current state
   bool prep_valid = false;
+  int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;

@@ -181,23 +181,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
 // part) and rhs.  grid = (ceil(35 V / 256), 48): slice g adds its share of the workspace rows and
 // finishes with one f64 atomic per element (48-way instead of 768-way contention).
 __global__ __launch_bounds__(256) void ba_cam_reduce_kernel(BaDev d, int nrows) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= d.V * 35) return;
-  const int per = (nrows + gridDim.y - 1) / gridDim.y;
-  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
-  double s = 0;
-  for (int r = r0; r < r1; ++r) s += d.lin_ws[(size_t)r * d.V * 35 + t];
-  if (s == 0.0) return;
-  const int c = t / 35, e = t % 35;
-  double* S = d.red;
-  double* rhs = d.red + (size_t)d.ld * d.ld;
-  if (e >= 28) {
-    atomicAdd(&rhs[7 * c + (e - 28)], s);
-  } else {
-    int i = 0, base = 0;                   // e = i(i+1)/2 + j
-    while (base + i + 1 <= e) { base += i + 1; ++i; }
-    atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + (e - base)], s);
-  }
+  cam_reduce_slice(d, nrows, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, gridDim.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,7 +753,8 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
     if (write_z) launch_linearize<0, true>(p, g, grid, 0, s, lambda, quirks);
     else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
   }
-  if (mode >= 1) {
+  p->lin_rows = mode >= 1 ? grid : 0;
+  if (mode >= 1 && write_z) {          // pair path: own launch; the MFMA path folds this sum into ba_schur_reduce_kernel
     dim3 rgrid((d.V * 35 + 255) / 256, 48);
     ba_cam_reduce_kernel<<<rgrid, 256, 0, s>>>(d, grid);
   }

@@ -312,7 +312,15 @@ constexpr size_t kSchurLdsBytes = sizeof(double) * (4 * STAGE + 2 * CB * 19);
 // S(lower) -= sum over the tile's chunk slabs, un-padding block coordinates (block b, row r) -> camera
 // b*CB + r/7, parameter r%7.  One thread per padded tile element; blockIdx.y slices the chunk range
 // (more loads in flight), one f64 atomic per slice and element.
-__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan) {
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan, int tile_blocks,
+                                                              int lin_rows) {
+  if ((int)blockIdx.x >= tile_blocks) {
+    // extra blocks: the camera-side sums of ba_linearize (U_c, rhs_c), 12 x gridDim.y slices
+    const int cam_blocks = (d.V * 35 + 255) / 256;
+    const int e = blockIdx.x - tile_blocks;
+    cam_reduce_slice(d, lin_rows, (e % cam_blocks) * 256 + threadIdx.x, (e / cam_blocks) * gridDim.y + blockIdx.y, 12 * gridDim.y);
+    return;
+  }
   const int ntiles = plan.n_off + plan.nblk;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ntiles * RB * RB) return;
@@ -419,7 +427,9 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     const int ntiles = pl.n_off + pl.nblk;
     double* ws = static_cast<double*>(p->schur_ws);
     ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, p->cur, p->quirks, p->schur_slot, p->schur_vpad, ws, pl);
-    ba_schur_reduce_kernel<<<dim3((ntiles * RB * RB + 255) / 256, 4), 256, 0, s>>>(d, ws, pl);
+    const int tile_blocks = (ntiles * RB * RB + 255) / 256;
+    const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
+    ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
   } else {
     const size_t lds = sizeof(double) * 21 * (size_t)std::max(1, p->max_track);
     if (lds > 64 * 1024) {

@@ -34,4 +34,19 @@ f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
 step 300 "$out/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
 step 300 "$out/pmc_write.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
 python3 tools/parse_pmc.py "$out/pmc_fetch" "$out/pmc_write" "$out/traffic.json"
+# matrix-pipe / LDS counters of every kernel (own pass, SQ block)
+step 300 "$out/pmc_sq.log" rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
+python3 - "$out/pmc_sq" "$out/pmc_sq_summary.csv" <<'PYEOF'
+import csv, glob, os, sys, collections
+files = glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)
+acc = collections.defaultdict(lambda: [0, 0.0])
+for f in files:
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])
+        acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
+w = csv.writer(open(sys.argv[2], "w")); w.writerow(["kernel", "counter", "dispatches", "avg_value"])
+for (k, c), (n, v) in sorted(acc.items()):
+    w.writerow([k, c, n, v / n])
+    if "schur_mfma" in k: print(k, c, n, v / n)
+PYEOF
 exit 0
