@@ -454,3 +454,111 @@ def rmse_pixels(cams, pts, cam_idx, pt_idx, uv_pix, intrinsic):
     pix = (np.asarray(intrinsic) @ p.T)
     uv = pix[0:2] / pix[2:3]
     return float(np.sqrt(np.mean(np.sum((uv - uv_pix) ** 2, axis=0))))
+
+
+# --------------------------------------------------------------------------------------
+# Two-view initialisation: epipolar_processor.py:22-267,
+# campose_processor.py:29-189
+# --------------------------------------------------------------------------------------
+def fund_normalize(left, right):
+    """epipolar_processor.py:97-137.  left/right: (>=2, n) pixel rows -> ((n,4) pairs, T_left, T_right)."""
+    n = left.shape[1]
+    lp, rp = left[0:2, :].T, right[0:2, :].T
+    lm, rm = np.average(lp, axis=0), np.average(rp, axis=0)
+    ls = (2 * n) ** 0.5 / np.sum((np.sum((lp - lm) ** 2, axis=1)) ** 0.5)
+    rs = (2 * n) ** 0.5 / np.sum((np.sum((rp - rm) ** 2, axis=1)) ** 0.5)
+    tl = np.array([[ls, 0, -lm[0] * ls], [0, ls, -lm[1] * ls], [0, 0, 1]])
+    tr = np.array([[rs, 0, -rm[0] * rs], [0, rs, -rm[1] * rs], [0, 0, 1]])
+    one = np.ones((n, 1))
+    ln = (tl @ np.column_stack((lp, one)).T).T
+    rn = (tr @ np.column_stack((rp, one)).T).T
+    return np.column_stack((ln[:, 0:2], rn[:, 0:2])), tl, tr
+
+
+def fund_eight_point(pairs8):
+    """epipolar_processor.py:140-193: null vector of the 8x9 system, rank-2 projection, / f[2][2]."""
+    w = np.zeros((8, 9))
+    for i in range(8):
+        x1, y1, x2, y2 = pairs8[i]
+        w[i] = [x1 * x2, y1 * x2, x2, x1 * y2, y1 * y2, y2, x1, y1, 1.0]
+    _, _, vh = np.linalg.svd(w)
+    f = np.reshape(vh.T[:, 8], (3, 3))
+    u, s, vh = np.linalg.svd(f)
+    f2 = u @ np.diag([s[0], s[1], 0]) @ vh
+    if np.linalg.matrix_rank(f2) != 2:
+        raise ValueError("f__ rank is not equal to 2")
+    return f2 / f2[2][2]
+
+
+def fund_ransac(pairs, samples, threshold):
+    """epipolar_processor.py:196-247 with the 8-index draws of ``random.sample`` passed in.
+    Returns (inlier index list or None, F (normalised coordinates), winning hypothesis or -1)."""
+    rows = pairs.shape[0]
+    if rows < 8:
+        raise ValueError("Insufficient matched pairs : {}".format(rows))
+    if rows == 8:
+        return list(range(8)), fund_eight_point(pairs), 0
+    xl = np.column_stack((pairs[:, 0:2], np.ones(rows)))
+    xr = np.column_stack((pairs[:, 2:4], np.ones(rows)))
+    best_n, best_idx, best_f, best_h = 0, None, np.zeros((3, 3)), -1
+    for h, idx in enumerate(samples):
+        f8 = fund_eight_point(pairs[list(idx), :])
+        val = np.abs(np.einsum('ni,ij,nj->n', xr, f8, xl))
+        inl = np.nonzero(val < threshold)[0]
+        if len(inl) > best_n:
+            best_n, best_idx, best_f, best_h = len(inl), [int(i) for i in inl], f8, h
+    return best_idx, best_f, best_h
+
+
+def fund_denormalize(f, tl, tr):
+    """epipolar_processor.py:251-267."""
+    g = tr.T @ f @ tl
+    return g / g[2][2]
+
+
+def determine_fundamental(left, right, samples, threshold):
+    """epipolar_processor.py:22-57: (inlier indices, fundamental matrix in pixel coordinates)."""
+    pairs, tl, tr = fund_normalize(left, right)
+    inl, f, _ = fund_ransac(pairs, samples, threshold)
+    return inl, fund_denormalize(f, tl, tr)
+
+
+def essential_from_fundamental(fund, left_k, right_k):
+    """epipolar_processor.py:60-95."""
+    e = right_k.T @ fund @ left_k
+    u, _, vh = np.linalg.svd(e)
+    e = u @ np.diag([1, 1, 0]) @ vh
+    if np.linalg.matrix_rank(e) != 2:
+        raise ValueError("esse_mat rank is not equal to 2")
+    return e / e[2][2]
+
+
+def pose_candidates(esse):
+    """campose_processor.py:29-100 -> (r1, r2, c1, c2).  The ORDER of (r1, r2) and the sign of c1
+    follow LAPACK's singular-vector signs; the set {r1, r2} x {c1, -c1} does not."""
+    w = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    u, _, vh = np.linalg.svd(esse)
+    c1 = u[:, 2].reshape(-1, 1)
+    r1, r2 = u @ w @ vh, u @ w.T @ vh
+    if np.linalg.det(r1) < 0:
+        r1 = -r1
+    if np.linalg.det(r2) < 0:
+        r2 = -r2
+    return r1.T, r2.T, c1, -c1
+
+
+def cheirality(p1, p2, pts_h):
+    """campose_processor.py:133-189: indices of the points in front of both cameras."""
+    z1 = (p1 @ pts_h)[2]
+    z2 = (p2 @ pts_h)[2]
+    return [int(i) for i in np.nonzero((z1 > 0) & (z2 > 0))[0]]
+
+
+def disambiguate(ref_proj, projs_four, pts_four):
+    """campose_processor.py:102-131: first candidate with the strictly largest valid count."""
+    best, best_n, best_idx = 0, 0, []
+    for i in range(4):
+        idx = cheirality(ref_proj, projs_four[i], pts_four[i])
+        if len(idx) > best_n:
+            best, best_n, best_idx = i, len(idx), idx
+    return best, best_idx

@@ -8,6 +8,11 @@
 
 namespace sfm {
 
+// Camera row blocks of the dense Schur product (sfm_ba_schur.hip): CB cameras = 126 rows, padded to RB = 128.
+constexpr int kSchurCB = 18;
+constexpr int kSchurRB = 128;
+constexpr int kSchurKSL = 32;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
+
 // Plain-data view passed by value to kernels (all pointers are device memory).
 struct BaDev {
   int V = 0, N = 0;
@@ -28,8 +33,11 @@ struct BaDev {
   // per-iteration scratch
   CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
   double* Z = nullptr;      // [21][M] (SoA)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j; pair-kernel path only (lazy)
+  double* Zd = nullptr;     // [zrows][zp] dense Z^T for the MFMA product: row 3p + j, column 128*(cam/18) + 7*(cam%18) + i;
+                            // entries of invisible (point, camera) pairs and all padding stay zero for the problem's lifetime
+  int zp = 0;               // row pitch of Zd = 128 * ceil(V / 18)
+  int zrows = 0;            // 3N rounded up to a multiple of kSchurKSL
   double* lin_ws = nullptr; // [linearize workgroups][V][35] per-workgroup camera accumulators (U lower 28 | rhs 7)
-  double* lip = nullptr;    // [N][6] L_p^-1 (lower, packed) of V_p = sum Jx^T Jx + lambda I
   double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
   double* delta = nullptr;  // [ld] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] Cholesky factors of the diagonal blocks
@@ -77,20 +85,19 @@ struct sfm_ba_problem {
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
-  int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight (the Schur producers re-derive it)
+  int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight
   int debug = 0;             // SFM_OPT_DEBUG: profiling ablations (results are wrong when set)
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
-  int* schur_slot = nullptr;     // [N][schur_vpad] observation index of (point, camera) or -1
-  int schur_vpad = 0;
   bool schur_mfma_ok = false;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 
 namespace sfm {
-int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx);
+int ba_schur_plan(sfm_ba_problem* p);
+int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);

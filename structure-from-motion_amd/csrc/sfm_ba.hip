@@ -42,10 +42,11 @@ __device__ __forceinline__ void obs_terms(const CamPrep& c, double X, double Y, 
                                           int quirks, double* r, double* Jp, double* Jx) {
   double p[3];
   project_cam(c, X, Y, Z, 1.0, p);
-  jac_cam(c, X, Y, Z, p, quirks, Jp);
-  jac_pt_cam(c, p, Jx);
-  r[0] = u - p[0] / p[2];      // b - f (ba:376)
-  r[1] = v - p[1] / p[2];
+  const double iz = 1.0 / p[2];          // one division per observation; f = p * iz (ba:339-342)
+  jac_cam_iz(c, X, Y, Z, p, iz, quirks, Jp);
+  jac_pt_cam_iz(c, p, iz, Jx);
+  r[0] = u - p[0] * iz;        // b - f (ba:376)
+  r[1] = v - p[1] * iz;
 }
 
 __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
@@ -60,7 +61,8 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // LDS_MODE 2: [V][19] prepared cameras + [V][35] camera-side accumulators in LDS (V <= 151);
 // LDS_MODE 1: accumulators only, cameras read from global/L2 (V <= 234); LDS_MODE 0: global atomics.
 // ---------------------------------------------------------------------------------------------
-template <int G, int LDS_MODE, bool WRITE_Z>
+// DENSE_Z: Z_o goes to its 7x3 slot of the dense Zd (MFMA product); otherwise to the SoA Z of the pair kernel.
+template <int G, int LDS_MODE, bool DENSE_Z>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
@@ -122,11 +124,11 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     const double y0 = li[0] * g3[0];
     const double y1 = li[1] * g3[0] + li[2] * g3[1];
     const double y2 = li[3] * g3[0] + li[4] * g3[1] + li[5] * g3[2];
-    if (!WRITE_Z && lane_g == 0 && p < d.N) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) d.lip[(size_t)p * 6 + k] = li[k];      // 48 B/point for the Schur producers
-    }
-    if (stamp && sidx < 60) { asm volatile("" :: "v"(y2)); stamp[sidx++] = __builtin_amdgcn_s_memtime(); }
+    // h = L^-T y = V^-1 g
+    const double h2 = li[5] * y2;
+    const double h1 = li[2] * y1 + li[4] * y2;
+    const double h0 = li[0] * y0 + li[1] * y1 + li[3] * y2;
+    if (stamp && sidx < 60) { asm volatile("" :: "v"(h0)); stamp[sidx++] = __builtin_amdgcn_s_memtime(); }
     const bool single = (end - beg) <= G;
     for (int o = beg + lane_g; o < end; o += G) {
       if (!single) {
@@ -135,23 +137,51 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
         load_cam(c, PREP_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
         obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
       }
-      double* zo = WRITE_Z ? d.Z + o : nullptr;   // SoA: element e of observation o at Z[e * M + o]
-      const size_t zs = (size_t)d.M;
       double acc[35];
+      {
+        // Z_o = (Jp^T Jx) L^-T = Jp^T (Jx L^-T): the 2x3 product first (ba:379 block B_{c,p})
+        double m0[3], m1[3];
+        m0[0] = Jx[0] * li[0];
+        m0[1] = Jx[0] * li[1] + Jx[1] * li[2];
+        m0[2] = Jx[0] * li[3] + Jx[1] * li[4] + Jx[2] * li[5];
+        m1[0] = Jx[3] * li[0];
+        m1[1] = Jx[3] * li[1] + Jx[4] * li[2];
+        m1[2] = Jx[3] * li[3] + Jx[4] * li[4] + Jx[5] * li[5];
+        if (DENSE_Z) {
+          const int blk = cam / kSchurCB;
+          double* zr = d.Zd + (size_t)(3 * p) * d.zp + blk * kSchurRB + 7 * (cam - blk * kSchurCB);
+          // 7 consecutive doubles per row, 8-byte aligned: three 16-byte stores + one 8-byte store per row
+          // (12 write requests per observation instead of 21; the request rate bounds this kernel's tail)
+          typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            double zz[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) zz[i] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
+            double* row = zr + (size_t)j * d.zp;
+#pragma unroll
+            for (int i = 0; i < 6; i += 2) *reinterpret_cast<d2u*>(row + i) = d2u{zz[i], zz[i + 1]};
+            row[6] = zz[6];
+          }
+        } else {
+          double* zo = d.Z + o;                       // SoA: element e of observation o at Z[e * M + o]
+          const size_t zs = (size_t)d.M;
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) zo[(3 * i + j) * zs] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
+          }
+        }
+      }
+      // rhs_c -= W V^-1 g = Jp^T (Jx h) with h = V^-1 g: folded into the residual, e = r - Jx h
+      const double e0 = r[0] - (Jx[0] * h0 + Jx[1] * h1 + Jx[2] * h2);
+      const double e1 = r[1] - (Jx[3] * h0 + Jx[4] * h1 + Jx[5] * h2);
       int k = 0;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        // W_i. = Jp[.][i]^T Jx (block B_{c,p}, ba:379);  Z_i. = W_i. L^-T
-        const double w0 = Jp[i] * Jx[0] + Jp[7 + i] * Jx[3];
-        const double w1 = Jp[i] * Jx[1] + Jp[7 + i] * Jx[4];
-        const double w2 = Jp[i] * Jx[2] + Jp[7 + i] * Jx[5];
-        const double z0 = w0 * li[0];
-        const double z1 = w0 * li[1] + w1 * li[2];
-        const double z2 = w0 * li[3] + w1 * li[4] + w2 * li[5];
-        if (WRITE_Z) { zo[(3 * i + 0) * zs] = z0; zo[(3 * i + 1) * zs] = z1; zo[(3 * i + 2) * zs] = z2; }
 #pragma unroll
         for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
-        acc[28 + i] = Jp[i] * r[0] + Jp[7 + i] * r[1] - (z0 * y0 + z1 * y1 + z2 * y2);
+        acc[28 + i] = Jp[i] * e0 + Jp[7 + i] * e1;
       }
       if (ACC_LDS) {
         double* a = lds_acc + (size_t)cam * 35;
@@ -737,24 +767,25 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);
   tick(p, SFM_K_LINEARIZE, true, s);
   p->quirks = quirks;
-  const bool write_z = !ba_schur_uses_mfma(p);
-  if (write_z && d.Z == nullptr && d.M > 0) {      // pair-kernel path: Z = (Jp^T Jx) L^-T is materialised (168 B/obs)
+  const bool dense_z = ba_schur_uses_mfma(p);
+  if (dense_z) SFM_TRY(ba_schur_prepare_dense(p, s));
+  if (!dense_z && d.Z == nullptr && d.M > 0) {     // pair-kernel path: Z as SoA [21][M] (168 B/obs)
     SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
   }
   const size_t lds_acc = sizeof(double) * (size_t)d.V * 35;
   const int mode = lds <= 64 * 1024 ? 2 : (lds_acc <= 64 * 1024 ? 1 : 0);
   if (mode == 2) {
-    if (write_z) launch_linearize<2, true>(p, g, grid, lds, s, lambda, quirks);
+    if (dense_z) launch_linearize<2, true>(p, g, grid, lds, s, lambda, quirks);
     else launch_linearize<2, false>(p, g, grid, lds, s, lambda, quirks);
   } else if (mode == 1) {
-    if (write_z) launch_linearize<1, true>(p, g, grid, lds_acc, s, lambda, quirks);
+    if (dense_z) launch_linearize<1, true>(p, g, grid, lds_acc, s, lambda, quirks);
     else launch_linearize<1, false>(p, g, grid, lds_acc, s, lambda, quirks);
   } else {
-    if (write_z) launch_linearize<0, true>(p, g, grid, 0, s, lambda, quirks);
+    if (dense_z) launch_linearize<0, true>(p, g, grid, 0, s, lambda, quirks);
     else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
   }
   p->lin_rows = mode >= 1 ? grid : 0;
-  if (mode >= 1 && write_z) {          // pair path: own launch; the MFMA path folds this sum into ba_schur_reduce_kernel
+  if (mode >= 1 && !dense_z) {         // pair path: own launch; the MFMA path folds this sum into ba_schur_reduce_kernel
     dim3 rgrid((d.V * 35 + 255) / 256, 48);
     ba_cam_reduce_kernel<<<rgrid, 256, 0, s>>>(d, grid);
   }
@@ -870,7 +901,6 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   BA_ALLOC(d.cams, (size_t)V * 7);
   BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
   BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
-  BA_ALLOC(d.lip, (size_t)N * 6);
   BA_ALLOC(d.lin_ws, (sizeof(double) * V * 35 <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
@@ -891,7 +921,7 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipStreamSynchronize(s) != hipSuccess) return fail(SFM_E_HIP);
-  { const int st_plan = ba_schur_plan(p, pt_ptr, cam_idx); if (st_plan != SFM_OK) return fail(st_plan); }
+  { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
   return SFM_OK;
 }
@@ -902,7 +932,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.lip, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws, p->schur_slot};
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

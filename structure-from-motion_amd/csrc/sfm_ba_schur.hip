@@ -6,10 +6,10 @@
 //                           (a >= b) x 49 entries as lane tasks, f64 atomics into S.  Work is
 //                           proportional to sum_p k_p (k_p+1)/2 (sparse-optimal); bound by the f64
 //                           atomic rate.  Used for small or sparse scenes.
-//   ba_schur_mfma_kernel    dense  v_mfma_f64_16x16x4_f64  SYRK over LDS images of Z^T that producer waves
-//                           re-derive from the 20 B/observation inputs (Z never touches HBM);
-//                           output-stationary 128x128 tiles x split-K chunks of points; no atomics.
-//                           Used when visibility is high enough that dense wins.
+//   ba_schur_mfma_kernel    dense  v_mfma_f64_16x16x4_f64  SYRK  S -= Zd^T Zd  over the dense matrix Zd
+//                           that ba_linearize fills (zeros where a point is not seen); panels are DMA'd
+//                           HBM -> LDS (global_load_lds); output-stationary 128x128 tiles x split-K row
+//                           chunks; no atomics.  Used when visibility is high enough that dense wins.
 #include <algorithm>
 #include <vector>
 
@@ -48,161 +48,106 @@ __global__ __launch_bounds__(64) void ba_schur_pairs_kernel(BaDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dense MFMA product, fused with the re-linearisation (no Z in HBM).
+// Dense MFMA product  S(lower) -= Zd^T Zd  over the materialised Z.
 //
-// Cameras are grouped into row blocks of CB = 18 (126 rows, padded to RB = 128 = 8 MFMA row strips),
-// so block boundaries never cut a camera.  Grid = (lower-triangular 128x128 output tiles) x (point
-// chunks).  One workgroup = 13 waves with fixed roles:
-//   * 5 producer waves: thread (which, point, camera slot) looks its observation up in the slot table
-//     (slot_obs[p][cam] = observation index or -1), reads the 16 B key and the point, re-derives
-//     Jp, Jx, W = Jp^T Jx and Z = W L_p^-T (L_p^-1 comes from ba_linearize, 48 B/point) and writes the
-//     camera's 7x3 block of Z -- or zeros -- to its fixed place in the [k][row] LDS image of the NEXT
-//     slab (8 points = 24 k-columns); the loads of the slab after that are already in flight.
-//   * 8 consumer waves: v_mfma_f64_16x16x4_f64 on the CURRENT slab.  Off-diagonal tiles: each wave
-//     owns 64x32 (4x2 MFMA tiles, 6 ds_read_b64 per 8 MFMAs).  Diagonal tiles: the 36 lower MFMA tiles
-//     are dealt round-robin (5,5,5,5,4,4,4,4: every SIMD gets 9), the 28 upper ones are never computed.
-// One __syncthreads per slab hands the double-buffered LDS image over.  A operand: lane l holds
-// A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
-// Partial tiles go to per-(chunk, tile) slabs (plain stores), summed into S by ba_schur_reduce_kernel.
+// ba_linearize writes every observation's 7x3 block Z_o into the dense matrix Zd[3N][zp] (row 3p + j, column
+// 128 * (cam / 18) + 7 * (cam % 18) + i; zeros where the point is not seen): cameras are grouped into column
+// blocks of CB = 18 (126 columns, padded to RB = 128 = 8 MFMA strips), so block boundaries never cut a
+// camera and a block's panel row is 1 KiB of contiguous memory.  The product is then a plain split-K SYRK:
+// grid = (lower-triangular 128x128 output tiles) x (row chunks of Zd); one workgroup = 8 waves.
+//   * staging: one  global_load_lds_dwordx4  per wave copies one 1 KiB panel row straight into the
+//     [k][ZLD] LDS image (no VGPRs, no FP64-pipe work); 32 rows x (1 or 2) panels per slab, double-buffered,
+//     the next slab's DMA is in flight while the current one is multiplied.
+//   * v_mfma_f64_16x16x4_f64: off-diagonal tiles give each wave 64x32 (4x2 MFMA tiles, 6 ds_read_b64 per 8
+//     MFMAs); diagonal tiles deal their 36 lower MFMA tiles round-robin (5,5,5,5,4,4,4,4: every SIMD gets 9),
+//     the 28 upper ones are never computed.
+// One barrier per slab.  A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15];
+// C/D: col = l&15, row = (l>>4) + 4*reg.  Partial tiles go to per-(chunk, tile) slabs (plain stores),
+// summed into S by ba_schur_reduce_kernel.
+// (r01..r02f fused the re-linearisation into producer waves of this kernel instead of reading Z; the
+// producers' FP64 VALU work interleaved badly with the MFMA stream -- 217 us vs the 170 us of the same
+// kernel with the producer math ablated -- see DESIGN.md section 8.)
 // ---------------------------------------------------------------------------------------------
 typedef double double4_ __attribute__((ext_vector_type(4)));
 
-constexpr int CB = 18;          // cameras per row block
-constexpr int RB = 128;         // padded rows per block
-constexpr int SP = 8;           // points per LDS slab
-constexpr int KSL = 3 * SP;     // k-columns per slab
-constexpr int ZLD = RB + 16;    // row pitch = 16 (mod 32) doubles: the k-rows of one ds_read_b64 hit disjoint banks
-constexpr int N_CONS = 8;       // consumer (MFMA) waves
-constexpr int N_PROD = 5;       // producer waves: 320 threads >= 2 * SP * CB = 288 staging tasks
-constexpr int SCHUR_THREADS = 64 * (N_CONS + N_PROD);
-constexpr int STAGE = KSL * ZLD;   // doubles per LDS image
+constexpr int CB = kSchurCB;     // cameras per column block
+constexpr int RB = kSchurRB;     // padded columns per block
+constexpr int KSL = kSchurKSL;   // Zd rows (k) per LDS slab
+constexpr int ZLD = RB + 16;     // LDS row pitch = 16 (mod 32) doubles: the k-rows of one ds_read_b64 hit disjoint banks
+constexpr int N_WAVES = 8;
+constexpr int SCHUR_THREADS = 64 * N_WAVES;
+constexpr int STAGE = KSL * ZLD;   // doubles per LDS panel image
+constexpr size_t kSchurLdsBytes = sizeof(double) * 4 * STAGE;   // 2 stages x 2 panels
 
-struct SlabIn {     // what one producer task needs for one slab
-  int o;            // observation index or -1
-  double u, v, X, Y, Z, li[6];
-};
-
-// The slot lookup and the loads that depend on it are issued in DIFFERENT slabs (slot two slabs ahead,
-// data one slab ahead), so no load latency is ever exposed on the producers' per-slab path.
-__device__ __forceinline__ int producer_slot(const BaDev& d, const int* __restrict__ slot_obs, int vpad, int p, int p_end,
-                                             int cam) {
-  return (p < p_end && cam < d.V) ? slot_obs[(size_t)p * vpad + cam] : -1;
-}
-
-__device__ __forceinline__ void producer_fetch(const BaDev& d, int o, int p, SlabIn& in) {
-  in.o = o;
-  if (o >= 0) {
-    in.u = d.u[o]; in.v = d.v[o];
-    in.X = d.px[p]; in.Y = d.py[p]; in.Z = d.pz[p];
+// One wave-instruction = 64 lanes x 16 B = one 1 KiB panel row; the LDS destination is wave-uniform.
+__device__ __forceinline__ void stage_panel(const double* __restrict__ g /* &Zd[k0][128 * blk] */, size_t zp,
+                                            double* __restrict__ image, int wave, int lane) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) in.li[k] = d.lip[(size_t)p * 6 + k];
+  for (int i = 0; i < KSL / N_WAVES; ++i) {
+    const int r = wave + N_WAVES * i;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)r * zp + 2 * lane),
+                                     (__attribute__((address_space(3))) void*)(image + r * ZLD), 16, 0, 0);
   }
 }
 
-__device__ __forceinline__ void producer_emit(const SlabIn& in, const double* __restrict__ cam_lds, int quirks,
-                                              double* __restrict__ dst /* &image[3*pl][7*cs] */) {
-  double z[21];
-  if (in.o >= 0) {
-    CamPrep c;
-    double* cd = reinterpret_cast<double*>(&c);
+// One slab of MFMAs with the operand reads of k-step kk+4 issued BEFORE the MFMAs of k-step kk (two operand
+// register sets), so the LDS latency hides behind the 8 (5, 4) MFMAs in between.
+// Off-diagonal tile: this wave's 64x32 part = 4 A strips x 2 B strips.
+__device__ __forceinline__ void slab_mma_off(const double* __restrict__ ra, const double* __restrict__ rc, double4_ (&acc)[8]) {
+  double a[2][4], b[2][2];
 #pragma unroll
-    for (int k = 0; k < 19; ++k) cd[k] = cam_lds[k];
-    double pc[3], Jp[14], Jx[6];
-    project_cam(c, in.X, in.Y, in.Z, 1.0, pc);
-    jac_cam(c, in.X, in.Y, in.Z, pc, quirks, Jp);
-    jac_pt_cam(c, pc, Jx);
-    // Z = (Jp^T Jx) Li^T = Jp^T (Jx Li^T): 2x3 product first, then 7 rows of 2 FMAs x 3
-    double m0[3], m1[3];
-    m0[0] = Jx[0] * in.li[0];
-    m0[1] = Jx[0] * in.li[1] + Jx[1] * in.li[2];
-    m0[2] = Jx[0] * in.li[3] + Jx[1] * in.li[4] + Jx[2] * in.li[5];
-    m1[0] = Jx[3] * in.li[0];
-    m1[1] = Jx[3] * in.li[1] + Jx[4] * in.li[2];
-    m1[2] = Jx[3] * in.li[3] + Jx[4] * in.li[4] + Jx[5] * in.li[5];
+  for (int x = 0; x < 4; ++x) a[0][x] = ra[16 * x];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+  for (int y = 0; y < 2; ++y) b[0][y] = rc[16 * y];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) z[3 * i + j] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
+  for (int kk = 0; kk < KSL; kk += 4) {
+    const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+    if (kk + 4 < KSL) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) a[nxt][x] = ra[(kk + 4) * ZLD + 16 * x];
+#pragma unroll
+      for (int y = 0; y < 2; ++y) b[nxt][y] = rc[(kk + 4) * ZLD + 16 * y];
     }
-  } else {
+    __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
-    for (int e = 0; e < 21; ++e) z[e] = 0.0;
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+        acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][x], b[cur][y], acc[2 * x + y], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-#pragma unroll
-  for (int e = 0; e < 21; ++e) dst[(e % 3) * ZLD + e / 3] = z[e];
 }
 
-// Slab hand-over barrier.  __syncthreads() would also wait for vmcnt(0) and so drain the producers'
-// prefetch of the slab after next; here only the LDS traffic has to be complete.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Diagonal tile: NS (5 or 4) lower 16x16 sub-tiles of this wave, operand offsets oa / ob in doubles.
+template <int NS>
+__device__ __forceinline__ void slab_mma_diag(const double* __restrict__ z, const int (&oa)[5], const int (&ob)[5],
+                                              double4_ (&acc)[8]) {
+  double a[2][NS], b[2][NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { a[0][s] = z[oa[s]]; b[0][s] = z[ob[s]]; }
+#pragma unroll
+  for (int kk = 0; kk < KSL; kk += 4) {
+    const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+    if (kk + 4 < KSL) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { a[nxt][s] = z[(kk + 4) * ZLD + oa[s]]; b[nxt][s] = z[(kk + 4) * ZLD + ob[s]]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][s], b[cur][s], acc[s], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 template <bool DIAG>
-__device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int quirks, const int* __restrict__ slot_obs,
-                                                int vpad, double* __restrict__ slab, int ti, int tj, int p_beg,
-                                                int p_end, double* __restrict__ img /*[2 stages][2][STAGE]*/,
-                                                double* __restrict__ cam_lds /*[2][CB][19]*/, int dbg) {
+__device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, size_t zp, double* __restrict__ slab, int ti,
+                                                int tj, int k_beg, int k_end, double* __restrict__ img /*[2][2][STAGE]*/,
+                                                int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool consumer = wave < N_CONS;
   const int lr = lane & 15, lk = lane >> 4;
+  const double* pa = Zd + (size_t)RB * ti;
+  const double* pb = Zd + (size_t)RB * tj;
 
-  // ---- one-time LDS setup: zero both stage images (padding rows stay zero), stage the cameras of both blocks
-  for (int t = tid; t < 4 * STAGE; t += SCHUR_THREADS) img[t] = 0.0;
-  {
-    const double* gprep = reinterpret_cast<const double*>(d.prep[cur]);
-    for (int t = tid; t < 2 * CB * 19; t += SCHUR_THREADS) {
-      const int which = t / (CB * 19), rem = t - which * (CB * 19);
-      const int cam = (which ? tj : ti) * CB + rem / 19;
-      cam_lds[t] = cam < d.V ? gprep[(size_t)cam * 19 + rem % 19] : 0.0;
-    }
-  }
-  __syncthreads();
-
-  // Producer and consumer waves run DIFFERENT loops with the same number of barriers, so the register
-  // allocator sees max(producer, consumer) pressure instead of their sum.
-  if (!consumer) {
-    // MFMA-f64 and VALU-f64 share one FP64 pipe per SIMD and the (older) consumer waves always have an
-    // MFMA ready: at equal priority the producers only get the pipe once the consumers sit at the slab
-    // barrier, which serialises the two phases.  With raised priority the producers' short dependent
-    // chains slot in between MFMAs and the slab is ready before the consumers need it.
-    __builtin_amdgcn_s_setprio(3);
-    constexpr int NTASK = (DIAG ? 1 : 2) * SP * CB;
-    const int ptid = tid - 64 * N_CONS;
-    const bool has_task = ptid < NTASK;
-    const int which = has_task ? ptid / (SP * CB) : 0;
-    const int tt = ptid - which * (SP * CB);
-    const int pl = has_task ? tt / CB : 0, cs = has_task ? tt - pl * CB : 0;
-    const int cam = (which ? tj : ti) * CB + cs;
-    const double* my_cam = cam_lds + (which * CB + cs) * 19;
-    const int dst_off = which * STAGE + 3 * pl * ZLD + 7 * cs;
-    SlabIn in;
-    in.o = -1;
-    int o_next = -1;
-    // prologue: image 0 <- slab 0; data of slab 1 and slot of slab 2 go in flight
-    if (has_task) {
-      producer_fetch(d, producer_slot(d, slot_obs, vpad, p_beg + pl, p_end, cam), p_beg + pl, in);
-      o_next = producer_slot(d, slot_obs, vpad, p_beg + SP + pl, p_end, cam);
-      producer_emit(in, my_cam, quirks, img + dst_off);
-      producer_fetch(d, o_next, p_beg + SP + pl, in);
-      o_next = producer_slot(d, slot_obs, vpad, p_beg + 2 * SP + pl, p_end, cam);
-    }
-    lds_barrier();
-    int stage = 0;
-    for (int ps = p_beg; ps < p_end; ps += SP, stage ^= 1) {
-      if (has_task && ps + SP < p_end) {
-        // image stage^1 <- slab ps+SP (data loaded one slab ago); data of slab ps+2SP (its slot was
-        // loaded one slab ago) and slot of slab ps+3SP go in flight
-        if (!(dbg & 2)) producer_emit(in, my_cam, quirks, img + (stage ^ 1) * 2 * STAGE + dst_off);
-        if (!(dbg & 4)) {
-          producer_fetch(d, o_next, ps + 2 * SP + pl, in);
-          o_next = producer_slot(d, slot_obs, vpad, ps + 3 * SP + pl, p_end, cam);
-        }
-      }
-      lds_barrier();
-    }
-    return;
-  }
-
-  // ---- consumer waves
   double4_ acc[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) acc[s] = double4_{0, 0, 0, 0};
@@ -210,7 +155,7 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
   int nsub = 0;
   if (DIAG) {
     for (int s = 0; s < 5; ++s) {
-      const int idx = wave + N_CONS * s;
+      const int idx = wave + N_WAVES * s;
       if (idx < 36) {
         int x = 0;
         while ((x + 1) * (x + 2) / 2 <= idx) ++x;
@@ -221,35 +166,34 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
     }
     nsub = __builtin_amdgcn_readfirstlane(nsub);
   }
+  int oa[5], ob[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) { oa[s] = 16 * sx[s]; ob[s] = 16 * sy[s]; }
   const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // off-diagonal tiles: this wave's 64x32 part
-  lds_barrier();                                           // prologue barrier (image 0 ready)
+
+  if (!(dbg & 4)) {
+    stage_panel(pa + (size_t)k_beg * zp, zp, img, wave, lane);
+    if (!DIAG) stage_panel(pb + (size_t)k_beg * zp, zp, img + STAGE, wave, lane);
+  }
   int stage = 0;
-  for (int ps = p_beg; ps < p_end; ps += SP, stage ^= 1) {
-    const double* za = img + stage * 2 * STAGE;
-    const double* zc = DIAG ? za : za + STAGE;
-    if (!(dbg & 1))
-#pragma unroll
-    for (int k0 = 0; k0 < KSL; k0 += 4) {
-      const double* ra = za + (k0 + lk) * ZLD + lr;
-      const double* rc = zc + (k0 + lk) * ZLD + lr;
+  for (int k0 = k_beg; k0 < k_end; k0 += KSL, stage ^= 1) {
+    // this wave's DMA of slab k0 has landed and its LDS reads of the previous slab are complete; after the
+    // barrier that holds for every wave, so slab k0 may be read and the other stage overwritten
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (k0 + KSL < k_end && !(dbg & 4)) {
+      double* nxt = img + (stage ^ 1) * 2 * STAGE;
+      stage_panel(pa + (size_t)(k0 + KSL) * zp, zp, nxt, wave, lane);
+      if (!DIAG) stage_panel(pb + (size_t)(k0 + KSL) * zp, zp, nxt + STAGE, wave, lane);
+    }
+    const double* za = img + stage * 2 * STAGE + lk * ZLD + lr;
+    if (!(dbg & 1)) {
       if (DIAG) {
-#pragma unroll
-        for (int s = 0; s < 5; ++s)
-          if (s < nsub) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[16 * sx[s]], rc[16 * sy[s]], acc[s], 0, 0, 0);
+        if (nsub == 5) slab_mma_diag<5>(za, oa, ob, acc);
+        else slab_mma_diag<4>(za, oa, ob, acc);
       } else {
-        double a[4], b[2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) a[x] = ra[wr + 16 * x];
-#pragma unroll
-        for (int y = 0; y < 2; ++y) b[y] = rc[wc + 16 * y];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-            acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[2 * x + y], 0, 0, 0);
+        slab_mma_off(za + wr, za + STAGE + wc, acc);
       }
     }
-    lds_barrier();
   }
   if (DIAG) {
 #pragma unroll
@@ -269,24 +213,20 @@ __device__ __forceinline__ void schur_tile_body(const BaDev& d, int cur, int qui
 }
 
 // Work split of the MFMA product.  A diagonal tile issues 9 MFMAs per SIMD and k-step, an
-// off-diagonal one 16, so diagonal tiles get proportionally longer point chunks: every workgroup then
-// carries the same MFMA load and the ~2 x CUs workgroups finish in two even rounds.  Workgroup w:
+// off-diagonal one 16, so diagonal tiles get proportionally longer row chunks: every workgroup then
+// carries the same MFMA load.  Workgroup w:
 //   w <  n_off * chunks_off : off-diagonal tile w / chunks_off (pairs ti > tj in row-major order)
 //   else                    : diagonal tile (w - n_off * chunks_off) / chunks_diag
 // and its partial tile goes to slab w.
 struct SchurPlan {
   int nblk, n_off;
-  int chunks_off, ppc_off;      // chunks per off-diagonal tile, points per chunk
-  int chunks_diag, ppc_diag;
-  int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 2 = no producer math, 4 = no producer loads
+  int chunks_off, rpc_off;      // chunks per off-diagonal tile, Zd rows per chunk
+  int chunks_diag, rpc_diag;
+  int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
 };
 
-__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, int cur, int quirks,
-                                                                    const int* __restrict__ slot_obs, int vpad,
-                                                                    double* __restrict__ ws, SchurPlan plan) {
-  extern __shared__ double lds_dyn[];
-  double* img = lds_dyn;                        // [2 stages][za, zb][KSL][ZLD]
-  double* cam_lds = lds_dyn + 4 * STAGE;        // [2 blocks][CB][19]
+__global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
+  extern __shared__ double img[];               // [2 stages][A panel, B panel][KSL][ZLD]
   const int w = blockIdx.x;
   const int off_wgs = plan.n_off * plan.chunks_off;
   double* slab = ws + (size_t)w * (RB * RB);
@@ -294,20 +234,18 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, i
     int t = w / plan.chunks_off, ti = 1;
     const int chunk = w - t * plan.chunks_off;
     while (t >= ti) { t -= ti; ++ti; }           // t-th pair (ti, tj) with ti > tj
-    const int p_beg = chunk * plan.ppc_off;
-    const int p_end = min(d.N, p_beg + plan.ppc_off);
-    schur_tile_body<false>(d, cur, quirks, slot_obs, vpad, slab, ti, t, p_beg, p_end, img, cam_lds, plan.dbg);
+    const int k_beg = chunk * plan.rpc_off;
+    const int k_end = min(d.zrows, k_beg + plan.rpc_off);
+    schur_tile_body<false>(d.Zd, (size_t)d.zp, slab, ti, t, k_beg, k_end, img, plan.dbg);
   } else {
     const int w2 = w - off_wgs;
     const int ti = w2 / plan.chunks_diag;
     const int chunk = w2 - ti * plan.chunks_diag;
-    const int p_beg = chunk * plan.ppc_diag;
-    const int p_end = min(d.N, p_beg + plan.ppc_diag);
-    schur_tile_body<true>(d, cur, quirks, slot_obs, vpad, slab, ti, ti, p_beg, p_end, img, cam_lds, plan.dbg);
+    const int k_beg = chunk * plan.rpc_diag;
+    const int k_end = min(d.zrows, k_beg + plan.rpc_diag);
+    schur_tile_body<true>(d.Zd, (size_t)d.zp, slab, ti, ti, k_beg, k_end, img, plan.dbg);
   }
 }
-
-constexpr size_t kSchurLdsBytes = sizeof(double) * (4 * STAGE + 2 * CB * 19);
 
 // S(lower) -= sum over the tile's chunk slabs, un-padding block coordinates (block b, row r) -> camera
 // b*CB + r/7, parameter r%7.  One thread per padded tile element; blockIdx.y slices the chunk range
@@ -358,48 +296,56 @@ static SchurPlan make_plan(const BaDev& d) {
   pl.dbg = 0;
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
-  const int slabs = std::max(1, (d.N + SP - 1) / SP);
-  // ONE workgroup per CU in total (each needs 116 KB of LDS, so a CU hosts one at a time): a single even
-  // round pays the per-workgroup setup / prologue / slab write once and halves the split-K slab traffic
+  const int slabs = std::max(1, d.zrows / KSL);
+  // ONE workgroup per CU in total (each needs 144 KB of LDS, so a CU hosts one at a time): a single even
+  // round pays the per-workgroup prologue / slab write once and halves the split-K slab traffic
   // compared with two rounds.  chunks_diag : chunks_off = 9 : 16; shrink until everything fits one round.
-  auto fit = [&](double want, int& chunks, int& ppc) {
+  auto fit = [&](double want, int& chunks, int& rpc) {
     int c = std::max(1, std::min(slabs, (int)(want + 0.5)));
     const int slabs_per = (slabs + c - 1) / c;
-    ppc = slabs_per * SP;
+    rpc = slabs_per * KSL;
     chunks = (slabs + slabs_per - 1) / slabs_per;
   };
   double target = (double)ctx().num_cus;
   for (int attempt = 0; attempt < 64; ++attempt) {
     const double a = target / (pl.n_off + (9.0 / 16.0) * pl.nblk);
-    fit(a, pl.chunks_off, pl.ppc_off);
-    fit(a * 9.0 / 16.0, pl.chunks_diag, pl.ppc_diag);
+    fit(a, pl.chunks_off, pl.rpc_off);
+    fit(a * 9.0 / 16.0, pl.chunks_diag, pl.rpc_diag);
     if (pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag <= ctx().num_cus || target < 8) break;
     target -= 1.0;
   }
-  if (pl.n_off == 0) { pl.chunks_off = 0; pl.ppc_off = SP; }
+  if (pl.n_off == 0) { pl.chunks_off = 0; pl.rpc_off = KSL; }
   return pl;
 }
 
-// Plan of the MFMA product: chunking of the points, slab workspace and the slot table.
-int ba_schur_plan(sfm_ba_problem* p, const int* pt_ptr, const int* cam_idx) {
-  const BaDev& d = p->dev;
+// Plan of the MFMA product: shape of Zd, chunking of its rows and the split-K slab workspace.  Zd itself is
+// allocated (and zero-filled) on first use by ba_schur_prepare_dense.
+int ba_schur_plan(sfm_ba_problem* p) {
+  BaDev& d = p->dev;
+  d.zp = RB * ((d.V + CB - 1) / CB);
+  d.zrows = ((3 * d.N + KSL - 1) / KSL) * KSL;
   const SchurPlan pl = make_plan(d);
   const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
-  p->schur_vpad = pl.nblk * CB;
   const size_t ws_bytes = sizeof(double) * (size_t)wgs * RB * RB;
-  const size_t slot_bytes = sizeof(int) * (size_t)std::max(1, d.N) * p->schur_vpad;
+  const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
   // the dense path is only ever chosen when it is cheaper than the pair path; do not reserve
-  // gigabytes for scenes that will never take it
-  p->schur_mfma_ok = ws_bytes + slot_bytes <= ((size_t)4 << 30);
+  // tens of gigabytes for scenes that will never take it
+  p->schur_mfma_ok = d.N > 0 && ws_bytes + zd_bytes <= ((size_t)32 << 30);
   if (!p->schur_mfma_ok) return SFM_OK;
   SFM_HIP(pool_alloc(&p->schur_ws, ws_bytes));
-  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_slot), slot_bytes));
-  std::vector<int> slot((size_t)std::max(1, d.N) * p->schur_vpad, -1);
-  for (int pt = 0; pt < d.N; ++pt)
-    for (int o = pt_ptr[pt]; o < pt_ptr[pt + 1]; ++o) slot[(size_t)pt * p->schur_vpad + cam_idx[o]] = o;
-  SFM_HIP(hipMemcpy(p->schur_slot, slot.data(), slot_bytes, hipMemcpyHostToDevice));
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
+  return SFM_OK;
+}
+
+// Zd on first use of the dense path: allocated once and cleared once -- ba_linearize rewrites every visible
+// (point, camera) block each iteration, everything else stays zero.
+int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
+  BaDev& d = p->dev;
+  if (d.Zd != nullptr) return SFM_OK;
+  const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&d.Zd), zd_bytes));
+  SFM_HIP(hipMemsetAsync(d.Zd, 0, zd_bytes, s));
   return SFM_OK;
 }
 
@@ -426,7 +372,7 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
     const int ntiles = pl.n_off + pl.nblk;
     double* ws = static_cast<double*>(p->schur_ws);
-    ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, p->cur, p->quirks, p->schur_slot, p->schur_vpad, ws, pl);
+    ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, ws, pl);
     const int tile_blocks = (ntiles * RB * RB + 255) / 256;
     const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
     ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);

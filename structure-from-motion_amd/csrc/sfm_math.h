@@ -112,27 +112,62 @@ SFM_HD void project_cam(const CamPrep& c, double X, double Y, double Z, double W
   p[2] = R[2] * X + R[5] * Y + R[8] * Z + c.t[2] * W;
 }
 
-// Jp (2x7, row-major Jp[7*row + col]) = [J_C | J_R J_q] for one (camera, point).
+// Jp (2x7, row-major Jp[7*row + col]) = [J_C | J_R J_q] for one (camera, point), given iz = 1/pz.
+// The reference forms J_R (2x9, campose_processor.py:742-766) and J_q (9x4, campose:654-700) and
+// multiplies them; here the product is factored as
+//   Jp_q[0][k] = (pz A_k - px C_k) / pz^2,  Jp_q[1][k] = (pz B_k - py C_k) / pz^2,
+//   (A,B,C)_k = sum_i d_i dR_{i0,i1,i2}/dq_k   with d = X - C (campose:735),
+// which is the same sum with the 11 structural zeros of J_q dropped (52 FMA-class ops instead of 96).
+SFM_HD void jac_cam_iz(const CamPrep& c, double X, double Y, double Z, const double* p, double iz, int quirks,
+                       double* Jp) {
+  const double* R = c.R;
+  const double px = p[0], py = p[1], pz = p[2];
+  const double iz2 = iz * iz;
+  const double d0 = X - c.C[0], d1 = Y - c.C[1], d2 = Z - c.C[2];
+  // J_C (campose_processor.py:798-806); Q2 keeps the reference's sign in the v-row
+  const double sgn = (quirks & SFM_Q2_LOC_JAC_SIGN) ? 1.0 : -1.0;
+  for (int i = 0; i < 3; ++i) {
+    Jp[i] = (px * R[3 * i + 2] - pz * R[3 * i + 0]) * iz2;
+    Jp[7 + i] = (-pz * R[3 * i + 1] - py * (sgn * R[3 * i + 2])) * iz2;
+  }
+  const double w2 = 2 * c.q[0], x2 = 2 * c.q[1], y2 = 2 * c.q[2], z2 = 2 * c.q[3];
+  const double x4 = 4 * c.q[1], y4 = 4 * c.q[2], z4 = 4 * c.q[3];
+  double A[4], B[4], C[4];
+  A[0] = d1 * z2 - d2 * y2;            B[0] = d2 * x2 - d0 * z2;            C[0] = d0 * y2 - d1 * x2;
+  A[1] = d1 * y2 + d2 * z2;            B[1] = d0 * y2 - d1 * x4 + d2 * w2;  C[1] = d0 * z2 - d1 * w2 - d2 * x4;
+  A[2] = d1 * x2 - d0 * y4 - d2 * w2;  B[2] = d0 * x2 + d2 * z2;            C[2] = d0 * w2 + d1 * z2 - d2 * y4;
+  A[3] = d1 * w2 - d0 * z4 + d2 * x2;  B[3] = d2 * y2 - d0 * w2 - d1 * z4;  C[3] = d0 * x2 + d1 * y2;
+  for (int k = 0; k < 4; ++k) {
+    Jp[3 + k] = (pz * A[k] - px * C[k]) * iz2;
+    Jp[10 + k] = (pz * B[k] - py * C[k]) * iz2;
+  }
+}
+
 SFM_HD void jac_cam(const CamPrep& c, double X, double Y, double Z, const double* p, int quirks,
                     double* Jp) {
+  jac_cam_iz(c, X, Y, Z, p, 1.0 / p[2], quirks, Jp);
+}
+
+// The same Jacobian as the literal product J_R (2x9) @ J_q (9x4) of the reference (campose:742-766, 654-700).
+// Kept beside the factored form: in the Schur producers, where the FP64 pipe is shared with MFMA, this
+// shape measured faster (profiles/r02g A/B), while the factored form wins in the streaming kernels.
+SFM_HD void jac_cam_table(const CamPrep& c, double X, double Y, double Z, const double* p, int quirks,
+                          double* Jp) {
   const double* R = c.R;
   const double px = p[0], py = p[1], pz = p[2];
   const double iz2 = 1.0 / (pz * pz);
-  const double d[3] = {X - c.C[0], Y - c.C[1], Z - c.C[2]};          // campose_processor.py:735
-  // J_C (campose_processor.py:798-806); Q2 keeps the reference's sign in the v-row
+  const double d[3] = {X - c.C[0], Y - c.C[1], Z - c.C[2]};
   const double sgn = (quirks & SFM_Q2_LOC_JAC_SIGN) ? 1.0 : -1.0;
   for (int i = 0; i < 3; ++i) {
     Jp[i] = (pz * -R[3 * i + 0] - px * -R[3 * i + 2]) * iz2;
     Jp[7 + i] = (pz * -R[3 * i + 1] - py * (sgn * R[3 * i + 2])) * iz2;
   }
-  // J_R (2x9, campose_processor.py:742-766): entries a_i = pz d_i / pz^2, bu_i = -px d_i / pz^2, bv_i = -py d_i / pz^2
   double a[3], bu[3], bv[3];
   for (int i = 0; i < 3; ++i) {
     a[i] = pz * d[i] * iz2;
     bu[i] = -px * d[i] * iz2;
     bv[i] = -py * d[i] * iz2;
   }
-  // J_q rows (campose_processor.py:654-700), row 3i+j <-> dR_ij/d(w,x,y,z)
   const double w2 = 2 * c.q[0], x2 = 2 * c.q[1], y2 = 2 * c.q[2], z2 = 2 * c.q[3];
   const double x4 = 4 * c.q[1], y4 = 4 * c.q[2], z4 = 4 * c.q[3];
   const double jq[9][4] = {{0, 0, -y4, -z4},   {-z2, y2, x2, -w2}, {y2, z2, w2, x2},
@@ -140,7 +175,7 @@ SFM_HD void jac_cam(const CamPrep& c, double X, double Y, double Z, const double
                            {-y2, z2, -w2, x2}, {x2, w2, z2, y2},   {0, -x4, -y4, 0}};
   for (int k = 0; k < 4; ++k) {
     double su = 0, sv = 0;
-    for (int i = 0; i < 3; ++i) {            // column order 3i, 3i+1, 3i+2 of J_R
+    for (int i = 0; i < 3; ++i) {
       su += a[i] * jq[3 * i + 0][k];
       sv += a[i] * jq[3 * i + 1][k];
       su += bu[i] * jq[3 * i + 2][k];
@@ -161,10 +196,19 @@ SFM_HD void jac_pt(const double* P, const double* s, double* Jx) {
   }
 }
 
-// Jx for the K-free projection [R^T | t] of a prepared camera (ba_processor.py:328, 333).
+// Jx for the K-free projection [R^T | t] of a prepared camera (ba_processor.py:328, 333), iz = 1/pz.
+SFM_HD void jac_pt_cam_iz(const CamPrep& c, const double* p, double iz, double* Jx) {
+  const double* R = c.R;
+  const double iz2 = iz * iz;
+  for (int j = 0; j < 3; ++j) {
+    Jx[j] = (p[2] * R[3 * j + 0] - p[0] * R[3 * j + 2]) * iz2;
+    Jx[3 + j] = (p[2] * R[3 * j + 1] - p[1] * R[3 * j + 2]) * iz2;
+  }
+}
+
 SFM_HD void jac_pt_cam(const CamPrep& c, const double* p, double* Jx) {
   const double* R = c.R;
-  const double iz2 = 1.0 / (p[2] * p[2]);
+  const double iz2 = 1.0 / (p[2] * p[2]);     // shares its division with jac_cam_table
   for (int j = 0; j < 3; ++j) {
     Jx[j] = (p[2] * R[3 * j + 0] - p[0] * R[3 * j + 2]) * iz2;
     Jx[3 + j] = (p[2] * R[3 * j + 1] - p[1] * R[3 * j + 2]) * iz2;

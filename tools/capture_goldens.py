@@ -417,6 +417,87 @@ def g7_visible(rng):
                         triples=np.array(triples, dtype=np.int64))
 
 
+def _text_points(path):
+    """The (x, y) rows of the reference's epipolar_set text files (first line = count)."""
+    with open(path) as f:
+        rows = [ln.split() for ln in f.read().strip().splitlines()]
+    rows = [r for r in rows if len(r) >= 2]
+    return np.array([[float(r[0]), float(r[1])] for r in rows])
+
+
+def g8_fundamental():
+    """Eight-point fundamental matrix + RANSAC (epipolar_processor.py:22-267)."""
+    import epipolar_processor as ref_epi
+    out = {}
+    # (i) the literal 8 pairs of the reference's unit test I (epipolar:283-290)
+    lit = np.array([[580, 2362, 492, 1803], [2050, 2097, 1381, 1956], [2558, 2174, 1544, 2115],
+                    [1395, 1970, 1166, 1752], [2490, 3003, 466, 2440], [3368, 1622, 3320, 2011],
+                    [2183, 1500, 2471, 1621], [1972, 1775, 1674, 1736]], dtype=float)
+    lp, rp = ref_utils.KeyPt(8), ref_utils.KeyPt(8)
+    lp[0:2, :] = lit[:, 0:2].T
+    rp[0:2, :] = lit[:, 2:4].T
+    cfg = quiet(ref_utils.RansacConfig, 1e-3, 0.99, 0.75, 8, 200)
+    ep = ref_epi.EpipolarProcessor(cfg)
+    inl = ep.determine_fundamental_mat([lp, rp], cfg)
+    out["lit_pairs"], out["lit_fund"], out["lit_inliers"] = lit, ep.fund_mat.copy(), np.array(inl)
+
+    # (ii) RANSAC runs: epipolar_set text points (unit test II: threshold 1, 300 its) and the opencv
+    # two-view pixel pairs with the demo's configuration (ba_processor.py:470-475: 1e-3, 300 its)
+    d = os.path.join(REF, "test_dataset")
+    p1 = _text_points(d + "/epipolar_set/pt_2D_1.txt")
+    p2 = _text_points(d + "/epipolar_set/pt_2D_2.txt")
+    k, _, _, kp1, kp2 = opencv_two_view()
+    for tag, left, right, thr, its in (("eps", p1.T, p2.T, 1.0, 300), ("ocv", np.asarray(kp1), np.asarray(kp2), 1e-3, 300)):
+        cfg = quiet(ref_utils.RansacConfig, thr, 0.99, 0.75, 8, its)
+        n = left.shape[1]
+        random.seed(1)
+        samples = np.array([random.sample(range(n), 8) for _ in range(cfg.iteration)])
+        ep = ref_epi.EpipolarProcessor(cfg)
+        pairs_norm, tl, tr = ep._EpipolarProcessor__normalize([left, right])
+        f_hyp = np.array([ep._EpipolarProcessor__estimate_eight_pts(pairs_norm[list(s), :]) for s in samples[:24]])
+        random.seed(1)
+        inl = ep.determine_fundamental_mat([left, right], cfg)
+        out.update({tag + "_left": left[0:2].copy(), tag + "_right": right[0:2].copy(), tag + "_threshold": thr,
+                    tag + "_samples": samples, tag + "_pairs_norm": pairs_norm, tag + "_tl": tl, tag + "_tr": tr,
+                    tag + "_f_hyp": f_hyp, tag + "_inliers": np.array(inl), tag + "_fund": ep.fund_mat.copy()})
+        if tag == "ocv":
+            ep.extract_essential_mat(k, k)
+            out["ocv_K"], out["ocv_esse"] = k, ep.esse_mat.copy()
+    np.savez_compressed(os.path.join(OUT, "g8_fundamental.npz"), **out)
+
+
+def g9_two_view_pose():
+    """Pose candidates from E, cheirality, disambiguation on the reference's own data files
+    (campose_processor.py:29-189; its unit test at campose:822-947)."""
+    d = os.path.join(REF, "test_dataset", "opencv")
+    esse = np.load(d + "/ess_ess_mat.npy")
+    k = np.load(d + "/ess_intrinsic_mat.npy")
+    ref_r = np.load(d + "/ess_self_r.npy").T
+    ref_c = np.load(d + "/ess_self_c.npy")
+    ref_proj = k @ np.hstack((ref_r.T, ref_r.T @ -ref_c))
+    cfg = quiet(ref_utils.RansacConfig, 8.0, 0.99, 0.75, 6, 300)
+    cp = ref_cam.CamposeProcessor(cfg, 5, 200)
+    r1, r2, c1, c2 = cp.extract_cam_pose_from_essential_mat(esse)
+    projs = [k @ np.hstack((r.T, -r.T @ c)) for r, c in ((r1, c1), (r1, c2), (r2, c1), (r2, c2))]
+    pts = [np.load(d + "/ess_points_3d_%s_result.npy" % t).T[0] for t in ("r1t1", "r1t2", "r2t1", "r2t2")]
+    valid = [cp.evalulate_cam_pose_cheirality(ref_proj, projs[i], pts[i]) for i in range(4)]
+    best, best_valid = cp.disambiguate_cam_pose_four(ref_proj, projs, pts)
+    # the reference's own linear triangulation of the four candidates on the matched pixel pairs (ba:89-93)
+    _, _, _, kp1, kp2 = opencv_two_view()
+    tp = ref_tri.TriangulationProcessor()
+    lin = [np.asarray(quiet(tp.linear_triangulate, [ref_proj, projs[i]], [kp1, kp2])) for i in range(4)]
+    best_lin, best_lin_valid = cp.disambiguate_cam_pose_four(ref_proj, projs, lin)
+    np.savez_compressed(os.path.join(OUT, "g9_two_view_pose.npz"), esse=esse, K=k, ref_proj=ref_proj,
+                        r1=r1, r2=r2, c1=c1, c2=c2,
+                        r1_truth=np.load(d + "/ess_r1.npy").T, r2_truth=np.load(d + "/ess_r2.npy").T,
+                        c1_truth=np.load(d + "/ess_c1.npy"), c2_truth=np.load(d + "/ess_c2.npy"),
+                        projs=np.array(projs), pts=np.array(pts), best=best, best_valid=np.array(best_valid),
+                        valid_counts=np.array([len(v) for v in valid]),
+                        valid1=np.array(valid[1]), left=np.asarray(kp1)[0:2], right=np.asarray(kp2)[0:2],
+                        lin_counts=np.array([len(cp.evalulate_cam_pose_cheirality(ref_proj, projs[i], lin[i])) for i in range(4)]),
+                        best_lin=best_lin, best_lin_valid=np.array(best_lin_valid), lin_best_pts=lin[best_lin])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
@@ -429,7 +510,7 @@ def main():
     random.seed(1)
     steps = [("g1", lambda: g1_jac_cam(rng)), ("g2", lambda: g2_jac_pt(rng)), ("g3", lambda: g3_quat(rng)),
              ("g4", lambda: g4_tri(rng, slow)), ("g5", lambda: g5_pnp(rng, slow)), ("g6", lambda: g6_ba(slow)),
-             ("g7", lambda: g7_visible(rng))]
+             ("g7", lambda: g7_visible(rng)), ("g8", g8_fundamental), ("g9", g9_two_view_pose)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

@@ -26,6 +26,8 @@ step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
 tail -1 "$out/bench_tri_pnp.log"
 step 240 "$out/bench_pairs.log" python bench.py --steps 5 --warmup 1 --schur pairs --no-cpu-baseline
 tail -1 "$out/bench_pairs.log"
+step 120 "$out/probe_schur.log" python tools/probe_schur.py
+tail -1 "$out/probe_schur.log"
 step 300 "$out/rocprof.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
 find "$out/prof" -name "*kernel_stats*" | head -3
 f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)

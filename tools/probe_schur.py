@@ -14,8 +14,7 @@ out = {}
 with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
     prob.set_option(native.OPT_SCHUR, native.SCHUR_MFMA)
     prob.set_option(native.OPT_TIMING, 1 << native.K_SCHUR)
-    for name, dbg in (("full", 0), ("no_mfma", 1), ("no_producer_math", 2), ("no_producer_math_no_loads", 6),
-                      ("no_mfma_no_math", 3), ("barriers_only", 7)):
+    for name, dbg in (("full", 0), ("no_mfma", 1), ("no_staging_loads", 4), ("barriers_only", 5)):
         prob.set_option(native.OPT_DEBUG, dbg)
         prob.set_state(sc.cams_init, sc.pts_init)
         prob.linearize_reduce(5.0)
