@@ -11,7 +11,7 @@ namespace sfm {
 // Camera row blocks of the dense Schur product (sfm_ba_schur.hip): CB cameras = 126 rows, padded to RB = 128.
 constexpr int kSchurCB = 18;
 constexpr int kSchurRB = 128;
-constexpr int kSchurKSL = 32;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
+constexpr int kSchurKSL = 16;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
 
 // Plain-data view passed by value to kernels (all pointers are device memory).
 struct BaDev {

@@ -11,6 +11,7 @@
 //                           HBM -> LDS (global_load_lds); output-stationary 128x128 tiles x split-K row
 //                           chunks; no atomics.  Used when visibility is high enough that dense wins.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "sfm_ba.h"
@@ -56,12 +57,12 @@ __global__ __launch_bounds__(64) void ba_schur_pairs_kernel(BaDev d) {
 // camera and a block's panel row is 1 KiB of contiguous memory.  The product is then a plain split-K SYRK:
 // grid = (lower-triangular 128x128 output tiles) x (row chunks of Zd); one workgroup = 8 waves.
 //   * staging: one  global_load_lds_dwordx4  per wave copies one 1 KiB panel row straight into the
-//     [k][ZLD] LDS image (no VGPRs, no FP64-pipe work); 32 rows x (1 or 2) panels per slab, double-buffered,
-//     the next slab's DMA is in flight while the current one is multiplied.
+//     [k][ZLD] LDS image (no VGPRs, no FP64-pipe work); 16 rows x (1 or 2) panels per slab in a ring of 4
+//     stages, the DMA running two slabs ahead of the MFMAs.
 //   * v_mfma_f64_16x16x4_f64: off-diagonal tiles give each wave 64x32 (4x2 MFMA tiles, 6 ds_read_b64 per 8
 //     MFMAs); diagonal tiles deal their 36 lower MFMA tiles round-robin (5,5,5,5,4,4,4,4: every SIMD gets 9),
 //     the 28 upper ones are never computed.
-// One barrier per slab.  A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15];
+// One barrier per slab, placed mid-slab (schur_k_loop).  A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15];
 // C/D: col = l&15, row = (l>>4) + 4*reg.  Partial tiles go to per-(chunk, tile) slabs (plain stores),
 // summed into S by ba_schur_reduce_kernel.
 // (r01..r02f fused the re-linearisation into producer waves of this kernel instead of reading Z; the
@@ -77,7 +78,9 @@ constexpr int ZLD = RB + 16;     // LDS row pitch = 16 (mod 32) doubles: the k-r
 constexpr int N_WAVES = 8;
 constexpr int SCHUR_THREADS = 64 * N_WAVES;
 constexpr int STAGE = KSL * ZLD;   // doubles per LDS panel image
-constexpr size_t kSchurLdsBytes = sizeof(double) * 4 * STAGE;   // 2 stages x 2 panels
+constexpr int NSTG = 4;            // ring of LDS stages (A panel + B panel each): DMA runs two slabs ahead
+constexpr size_t kSchurLdsBytes = sizeof(double) * NSTG * 2 * STAGE;   // 147456 B
+static_assert(KSL == 16 && N_WAVES == 8, "schur_k_loop is written for 4 k-steps per slab and 2 DMA rows per wave and panel");
 
 // One wave-instruction = 64 lanes x 16 B = one 1 KiB panel row; the LDS destination is wave-uniform.
 __device__ __forceinline__ void stage_panel(const double* __restrict__ g /* &Zd[k0][128 * blk] */, size_t zp,
@@ -90,58 +93,100 @@ __device__ __forceinline__ void stage_panel(const double* __restrict__ g /* &Zd[
   }
 }
 
-// One slab of MFMAs with the operand reads of k-step kk+4 issued BEFORE the MFMAs of k-step kk (two operand
-// register sets), so the LDS latency hides behind the 8 (5, 4) MFMAs in between.
-// Off-diagonal tile: this wave's 64x32 part = 4 A strips x 2 B strips.
-__device__ __forceinline__ void slab_mma_off(const double* __restrict__ ra, const double* __restrict__ rc, double4_ (&acc)[8]) {
-  double a[2][4], b[2][2];
+// The k loop of one tile: a ring of NSTG LDS stages of KSL = 16 rows (4 MFMA k-steps), two operand register
+// sets.  Per slab s:
+//   k-step 0, 1      reads of the next k-step are issued BEFORE the MFMAs of the current one
+//   mid-slab         s_waitcnt vmcnt(batch)  -> this wave's DMA of slab s+1 (issued two slabs ago) has landed
+//                    s_barrier               -> ... and everybody's; every wave is past slab s-1
+//                    DMA of slab s+3 into the stage slab s-1 occupied
+//   k-step 2, 3      the reads issued during k-step 3 are k-step 0 of slab s+1
+// so neither the barrier nor the slab hand-over ever leaves the MFMA pipe without a ready operand set (with
+// the barrier at the slab boundary both waves of a SIMD stalled there together: ~1.3k cycles per slab).
+// s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields left at "no wait"); the builtin, unlike inline asm, keeps the
+// compiler's own counter bookkeeping exact, so it does not fall back to lgkmcnt(0) before the next MFMA
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70 | N); }
+
+template <bool DIAG, int NS, bool MMA, bool LOADS>
+__device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, const double* __restrict__ pb, size_t zp,
+                                             int k_beg, int nslab, double* __restrict__ img, const int (&oa)[5],
+                                             const int (&ob)[5], int wr, int wc, double4_ (&acc)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NA = DIAG ? NS : 4, NB = DIAG ? NS : 2;
+  constexpr int BATCH = (DIAG ? 1 : 2) * (KSL / N_WAVES);      // DMA instructions per wave and slab
+  double a[2][NA], b[2][NB];
+  const double* z0 = img + (lane >> 4) * ZLD + (lane & 15);
+  auto load_ops = [&](int set, int s, int krow) {
+    const double* z = z0 + (s & (NSTG - 1)) * 2 * STAGE + krow * ZLD;
+    if (DIAG) {
 #pragma unroll
-  for (int x = 0; x < 4; ++x) a[0][x] = ra[16 * x];
+      for (int t = 0; t < NS; ++t) { a[set][t] = z[oa[t]]; b[set][t] = z[ob[t]]; }
+    } else {
 #pragma unroll
-  for (int y = 0; y < 2; ++y) b[0][y] = rc[16 * y];
+      for (int x = 0; x < 4; ++x) a[set][x] = z[wr + 16 * x];
 #pragma unroll
-  for (int kk = 0; kk < KSL; kk += 4) {
-    const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
-    if (kk + 4 < KSL) {
-#pragma unroll
-      for (int x = 0; x < 4; ++x) a[nxt][x] = ra[(kk + 4) * ZLD + 16 * x];
-#pragma unroll
-      for (int y = 0; y < 2; ++y) b[nxt][y] = rc[(kk + 4) * ZLD + 16 * y];
+      for (int y = 0; y < 2; ++y) b[set][y] = z[STAGE + wc + 16 * y];
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
+  };
+  auto mma = [&](int set) {
+    if (MMA) {
+      if (DIAG) {
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][t], b[set][t], acc[t], 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int y = 0; y < 2; ++y)
-        acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][x], b[cur][y], acc[2 * x + y], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Diagonal tile: NS (5 or 4) lower 16x16 sub-tiles of this wave, operand offsets oa / ob in doubles.
-template <int NS>
-__device__ __forceinline__ void slab_mma_diag(const double* __restrict__ z, const int (&oa)[5], const int (&ob)[5],
-                                              double4_ (&acc)[8]) {
-  double a[2][NS], b[2][NS];
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-  for (int s = 0; s < NS; ++s) { a[0][s] = z[oa[s]]; b[0][s] = z[ob[s]]; }
-#pragma unroll
-  for (int kk = 0; kk < KSL; kk += 4) {
-    const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
-    if (kk + 4 < KSL) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) { a[nxt][s] = z[(kk + 4) * ZLD + oa[s]]; b[nxt][s] = z[(kk + 4) * ZLD + ob[s]]; }
+          for (int y = 0; y < 2; ++y)
+            acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][x], b[set][y], acc[2 * x + y], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][s], b[cur][s], acc[s], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  };
+  auto issue = [&](int s) {
+    if (!LOADS) return;
+    double* st = img + (s & (NSTG - 1)) * 2 * STAGE;
+    const size_t row = (size_t)(k_beg + s * KSL) * zp;
+    stage_panel(pa + row, zp, st, wave, lane);
+    if (!DIAG) stage_panel(pb + row, zp, st + STAGE, wave, lane);
+  };
+  // one slab; the flags say whether slabs s+1, s+2, s+3 exist (compile-time, so the steady-state loop body is a
+  // single basic block and the compiler's s_waitcnt placement stays exact)
+  auto slab = [&](int s, auto has1, auto has2, auto has3) {
+    load_ops(1, s, 4);
+    mma(0);
+    load_ops(0, s, 8);
+    mma(1);
+    if constexpr (decltype(has1)::value) {
+      if constexpr (decltype(has2)::value) wait_vmcnt<BATCH>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if constexpr (decltype(has3)::value) issue(s + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_ops(1, s, 12);
+    mma(0);
+    if constexpr (decltype(has1)::value) load_ops(0, s + 1, 0);
+    mma(1);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  issue(0);
+  if (nslab > 1) issue(1);
+  if (nslab > 1) wait_vmcnt<BATCH>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (nslab > 2) issue(2);
+  load_ops(0, 0, 0);
+  int s = 0;
+  for (; s + 3 < nslab; ++s) slab(s, T{}, T{}, T{});
+  if (s + 2 < nslab) { slab(s, T{}, T{}, F{}); ++s; }
+  if (s + 1 < nslab) { slab(s, T{}, F{}, F{}); ++s; }
+  if (s < nslab) slab(s, F{}, F{}, F{});
 }
 
 template <bool DIAG>
 __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, size_t zp, double* __restrict__ slab, int ti,
-                                                int tj, int k_beg, int k_end, double* __restrict__ img /*[2][2][STAGE]*/,
+                                                int tj, int k_beg, int k_end, double* __restrict__ img /*[NSTG][2][STAGE]*/,
                                                 int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -170,30 +215,23 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
 #pragma unroll
   for (int s = 0; s < 5; ++s) { oa[s] = 16 * sx[s]; ob[s] = 16 * sy[s]; }
   const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // off-diagonal tiles: this wave's 64x32 part
-
-  if (!(dbg & 4)) {
-    stage_panel(pa + (size_t)k_beg * zp, zp, img, wave, lane);
-    if (!DIAG) stage_panel(pb + (size_t)k_beg * zp, zp, img + STAGE, wave, lane);
-  }
-  int stage = 0;
-  for (int k0 = k_beg; k0 < k_end; k0 += KSL, stage ^= 1) {
-    // this wave's DMA of slab k0 has landed and its LDS reads of the previous slab are complete; after the
-    // barrier that holds for every wave, so slab k0 may be read and the other stage overwritten
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (k0 + KSL < k_end && !(dbg & 4)) {
-      double* nxt = img + (stage ^ 1) * 2 * STAGE;
-      stage_panel(pa + (size_t)(k0 + KSL) * zp, zp, nxt, wave, lane);
-      if (!DIAG) stage_panel(pb + (size_t)(k0 + KSL) * zp, zp, nxt + STAGE, wave, lane);
+  const int nslab = (k_end - k_beg) / KSL;                   // chunk bounds are multiples of KSL
+  if (dbg & 5) {      // profiling ablations (1: no MFMA, 4: no staging DMA); results are wrong by design
+    const bool mm = !(dbg & 1), ld = !(dbg & 4);
+    if (DIAG) {
+      if (mm) schur_k_loop<true, 5, true, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      else if (ld) schur_k_loop<true, 5, false, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      else schur_k_loop<true, 5, false, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+    } else {
+      if (mm) schur_k_loop<false, 4, true, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      else if (ld) schur_k_loop<false, 4, false, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      else schur_k_loop<false, 4, false, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
     }
-    const double* za = img + stage * 2 * STAGE + lk * ZLD + lr;
-    if (!(dbg & 1)) {
-      if (DIAG) {
-        if (nsub == 5) slab_mma_diag<5>(za, oa, ob, acc);
-        else slab_mma_diag<4>(za, oa, ob, acc);
-      } else {
-        slab_mma_off(za + wr, za + STAGE + wc, acc);
-      }
-    }
+  } else if (DIAG) {
+    if (nsub == 5) schur_k_loop<true, 5, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+    else schur_k_loop<true, 4, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+  } else {
+    schur_k_loop<false, 4, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
   }
   if (DIAG) {
 #pragma unroll
@@ -226,7 +264,7 @@ struct SchurPlan {
 };
 
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
-  extern __shared__ double img[];               // [2 stages][A panel, B panel][KSL][ZLD]
+  extern __shared__ double img[];               // [NSTG stages][A panel, B panel][KSL][ZLD]
   const int w = blockIdx.x;
   const int off_wgs = plan.n_off * plan.chunks_off;
   double* slab = ws + (size_t)w * (RB * RB);
