@@ -35,6 +35,7 @@ extern "C" {
 #define SFM_E_HIP           -5   /* HIP runtime error */
 #define SFM_E_NO_DEVICE     -6   /* no gfx950 device visible */
 #define SFM_E_HANDLE        -7   /* null / destroyed problem handle */
+#define SFM_E_RANK          -8   /* rank-2 projection of a fundamental / essential matrix is not rank 2 -> ValueError (epipolar_processor.py:187-190, 90-93) */
 
 /* ---- quirk bits; the reference's behaviour = SFM_QUIRKS_REFERENCE ------ */
 #define SFM_Q1_PNP_ROW_OVERLAP  1  /* campose_processor.py:404-405: rows stored at [pt:pt+2] */
@@ -121,6 +122,39 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix /*[3][n]*/, const double* 
                           int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
                           double R_out[9], double C_out[3], int* inlier_mask /*[n]*/, int* n_inliers,
                           int* best_hypothesis);
+
+/* ---- Two-view initialisation ------------------------------------------------- */
+/* EpipolarProcessor.determine_fundamental_mat (epipolar_processor.py:22-57 = __normalize 97-137,
+ * __estimate_ransac 196-247 over __estimate_eight_pts 140-193, __denormalize 251-267).  left/right are rows 0-1
+ * of the matched KeyPt arrays.  The caller draws the n_hyp eight-index samples (Python's `random.sample`,
+ * epipolar:225); the device normalises the points, solves every hypothesis (8x9 null vector, rank-2 projection,
+ * / f[2][2]), scores |x_r^T F x_l| < threshold on the normalised pairs and returns the FIRST hypothesis with
+ * the largest inlier count, de-normalised and divided by F[2][2].  n == 8: the single estimate from all eight
+ * pairs, every pair an inlier (epipolar:219-221; samples/n_hyp ignored).  n < 8: SFM_E_SHAPE.  A hypothesis whose
+ * rank-2 projection has rank != 2: SFM_E_RANK (the reference raises ValueError, epipolar:187-190).  No hypothesis
+ * with an inlier: *best_hypothesis = -1, mask all zero, F = NaN (the reference divides its zero matrix by
+ * F[2][2] = 0, epipolar:216, 266). */
+int sfm_fundamental_ransac(int n, const double* left /*[2][n]*/, const double* right /*[2][n]*/, int n_hyp,
+                           const int* samples /*[n_hyp][8]*/, double threshold, double F_out[9],
+                           int* inlier_mask /*[n]*/, int* n_inliers, int* best_hypothesis);
+/* Parity hook: EpipolarProcessor.__estimate_eight_pts (epipolar_processor.py:140-193) for n_hyp samples of the
+ * given (already normalised) pairs [n][4] = (x_l, y_l, x_r, y_r).  status[h] = SFM_OK / SFM_E_RANK. */
+int sfm_fundamental_eight_point(int n, const double* pairs /*[n][4]*/, int n_hyp, const int* samples /*[n_hyp][8]*/,
+                                double* F_out /*[n_hyp][9]*/, int* status /*[n_hyp]*/);
+/* EpipolarProcessor.extract_essential_mat (epipolar_processor.py:60-95): E = U diag(1,1,0) V^T of
+ * K_right^T F K_left, divided by E[2][2]. */
+int sfm_essential_from_fundamental(const double F[9], const double K_left[9], const double K_right[9], double E_out[9]);
+/* CamposeProcessor.extract_cam_pose_from_essential_mat (campose_processor.py:29-100): the two rotations
+ * (R_out[0], R_out[1], camera->world convention of the reference's return value) and the centre c1 (c2 = -c1).
+ * The reference's ORDER of (r1, r2) and SIGN of c1 follow LAPACK's singular-vector signs; the set of four
+ * candidates {r1, r2} x {c1, -c1} is what is defined, and what callers (ba_processor.py:81-97) consume. */
+int sfm_pose_candidates(const double E[9], double R_out[18], double C1_out[3]);
+/* CamposeProcessor.evalulate_cam_pose_cheirality / disambiguate_cam_pose_four (campose_processor.py:102-189)
+ * for k candidate (projection, point set) pairs against the reference projection P1: mask[c][i] = both depths
+ * (third rows of P1 X, P2_c X) positive, counts[c] = their number, *best = FIRST candidate with the strictly
+ * largest count starting from 0 (so 0 if no candidate has a valid point). */
+int sfm_cheirality(int k, int n, const double P1[12], const double* P2 /*[k][12]*/, const double* X /*[k][4][n]*/,
+                   int* mask /*[k][n]*/, int* counts /*[k]*/, int* best);
 
 /* ---- BaProcessor.__execute_bundle_adjustment (ba_processor.py:274-439) ------------------------- */
 /* Observations are sorted by (point, camera) — the reference's loop order (ba_processor.py:304-306)

@@ -125,4 +125,35 @@ __device__ __forceinline__ void chol3_inv_fast(const double* a, double* li) {
 
 __device__ __forceinline__ double wave_sum(double v) { return group_sum<64>(v); }
 
+// One-sided Jacobi on the columns of B (N x N, row-major B[row][col]): on return the columns of B are
+// mutually orthogonal (B_out = B_in V, column c = sigma_c u_c) and V holds the right singular vectors as
+// columns.  Column order is whatever the sweeps leave; callers pick columns by norm.
+template <int N>
+__device__ void jacobi_right_vectors(double (&B)[N][N], double (&V)[N][N], int max_sweeps) {
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < N - 1; ++p) {
+      for (int q = p + 1; q < N; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < N; ++k) { al += B[k][p] * B[k][p]; be += B[k][q] * B[k][q]; ga += B[k][p] * B[k][q]; }
+        if (ga != 0.0 && fabs(ga) > 1e-17 * sqrt(al * be)) {
+          rotated = true;
+          const double ze = (be - al) / (2.0 * ga);
+          const double t = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
+          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+          for (int k = 0; k < N; ++k) {
+            const double bp = B[k][p], bq = B[k][q];
+            B[k][p] = c * bp - sn * bq; B[k][q] = sn * bp + c * bq;
+            const double vp = V[k][p], vq = V[k][q];
+            V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
+          }
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+}
+
 }  // namespace sfm

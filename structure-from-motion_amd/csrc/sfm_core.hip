@@ -487,34 +487,6 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
 //                          threshold (campose:544-554) -> inlier count
 //   pnp_inlier_mask_kernel inlier mask of the winning hypothesis
 // ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ void jacobi_right_vectors(double (&B)[N][N], double (&V)[N][N], int max_sweeps) {
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    bool rotated = false;
-    for (int p = 0; p < N - 1; ++p) {
-      for (int q = p + 1; q < N; ++q) {
-        double al = 0, be = 0, ga = 0;
-        for (int k = 0; k < N; ++k) { al += B[k][p] * B[k][p]; be += B[k][q] * B[k][q]; ga += B[k][p] * B[k][q]; }
-        if (ga != 0.0 && fabs(ga) > 1e-17 * sqrt(al * be)) {
-          rotated = true;
-          const double ze = (be - al) / (2.0 * ga);
-          const double t = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
-          const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-          for (int k = 0; k < N; ++k) {
-            const double bp = B[k][p], bq = B[k][q];
-            B[k][p] = c * bp - sn * bq; B[k][q] = sn * bp + c * bq;
-            const double vp = V[k][p], vq = V[k][q];
-            V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
-          }
-        }
-      }
-    }
-    if (!rotated) break;
-  }
-}
-
 __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, const int* __restrict__ samples /*[n_hyp][6]*/,
                                                            const double* __restrict__ uv_pix /*[3][n]*/,
                                                            const double* __restrict__ X /*[4][n]*/,

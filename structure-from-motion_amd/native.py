@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsfm_hip.so")
 
 OK = 0
-E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE = -1, -2, -3, -4, -5, -6, -7
+E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK = -1, -2, -3, -4, -5, -6, -7, -8
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
 SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA = 0, 1, 2
 OPT_SCHUR, OPT_TIMING, OPT_DEBUG = 1, 2, 3
@@ -26,6 +26,8 @@ EXPORTS = (
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_pnp_linear_ransac",
+    "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
+    "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
@@ -97,6 +99,10 @@ def load():
     lib.sfm_rot_to_quat.argtypes = [ctypes.c_int, _dp, _dp, _ip]
     lib.sfm_jac_cam.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _dp, _ip]
     lib.sfm_jac_pt.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp]
+    lib.sfm_fundamental_eight_point.argtypes = [ctypes.c_int, _dp, ctypes.c_int, _ip, _dp, _ip]
+    lib.sfm_essential_from_fundamental.argtypes = [_dp, _dp, _dp, _dp]
+    lib.sfm_pose_candidates.argtypes = [_dp, _dp, _dp]
+    lib.sfm_cheirality.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _ip, _ip, _ip]
     _lib = lib
     return lib
 
@@ -117,6 +123,8 @@ def check(status):
     if status == E_SQRT_DOMAIN:
         raise ValueError("math domain error (%s)" % msg)
     if status == E_SHAPE:
+        raise ValueError(msg)
+    if status == E_RANK:
         raise ValueError(msg)
     raise SfmHipError("libsfm_hip status %d: %s" % (status, msg))
 
@@ -234,6 +242,58 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
                                     float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
                                     ctypes.byref(best)))
     return rot, loc.reshape(3, 1), [int(i) for i in np.flatnonzero(mask)], best.value
+
+
+def fundamental_ransac(left, right, samples, threshold):
+    """Eight-point RANSAC (epipolar_processor.py:22-57).  left/right: (>=2, n) pixel rows; samples: (n_hyp, 8)
+    indices drawn by the caller (ignored when n == 8).  Returns (F (3,3), inlier index list or None, best
+    hypothesis index or -1)."""
+    left = f64(np.asarray(left)[0:2]); right = f64(np.asarray(right)[0:2])
+    n = left.shape[1]
+    samples = i32(samples if samples is not None and n != 8 else np.arange(8)).reshape(-1, 8)
+    fund = np.empty((3, 3)); mask = np.empty(max(n, 1), dtype=np.int32)
+    cnt = ctypes.c_int(); best = ctypes.c_int()
+    lib = load()
+    lib.sfm_fundamental_ransac.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _ip, ctypes.c_double, _dp, _ip, _ip, _ip]
+    check(lib.sfm_fundamental_ransac(n, dptr(left), dptr(right), samples.shape[0], iptr(samples), float(threshold),
+                                     dptr(fund), iptr(mask), ctypes.byref(cnt), ctypes.byref(best)))
+    inliers = None if best.value < 0 else [int(i) for i in np.flatnonzero(mask[:n])]
+    return fund, inliers, best.value
+
+
+def fundamental_eight_point(pairs, samples):
+    """epipolar_processor.py:140-193 for every 8-index sample of the normalised pairs (n, 4) -> (F (n_hyp,3,3), status)."""
+    pairs = f64(pairs); samples = i32(samples).reshape(-1, 8)
+    out = np.empty((samples.shape[0], 3, 3)); st = np.empty(samples.shape[0], dtype=np.int32)
+    check(load().sfm_fundamental_eight_point(pairs.shape[0], dptr(pairs), samples.shape[0], iptr(samples), dptr(out), iptr(st)))
+    return out, st
+
+
+def essential_from_fundamental(fund, left_k, right_k):
+    """epipolar_processor.py:60-95."""
+    fund = f64(fund); left_k = f64(left_k); right_k = f64(right_k)
+    out = np.empty((3, 3))
+    check(load().sfm_essential_from_fundamental(dptr(fund), dptr(left_k), dptr(right_k), dptr(out)))
+    return out
+
+
+def pose_candidates(esse):
+    """campose_processor.py:29-100 -> (r1, r2, c1 (3,1), c2 = -c1)."""
+    esse = f64(esse)
+    rots = np.empty((2, 3, 3)); c1 = np.empty(3)
+    check(load().sfm_pose_candidates(dptr(esse), dptr(rots), dptr(c1)))
+    return rots[0].copy(), rots[1].copy(), c1.reshape(3, 1).copy(), -c1.reshape(3, 1)
+
+
+def cheirality(ref_proj, projs, pts_sets):
+    """campose_processor.py:102-189 for k candidates: projs (k,3,4), pts_sets (k,4,n) -> (masks (k,n), counts (k,), best)."""
+    ref_proj = f64(ref_proj); projs = f64(projs).reshape(-1, 3, 4)
+    pts_sets = f64(pts_sets).reshape(projs.shape[0], 4, -1)
+    k, n = projs.shape[0], pts_sets.shape[2]
+    mask = np.zeros((k, max(n, 1)), dtype=np.int32); counts = np.zeros(k, dtype=np.int32)
+    best = ctypes.c_int()
+    check(load().sfm_cheirality(k, n, dptr(ref_proj), dptr(projs), dptr(pts_sets), iptr(mask), iptr(counts), ctypes.byref(best)))
+    return mask[:, :n], counts, best.value
 
 
 def pnp_nonlinear_batch(offsets, uv_pix, pts_h, intrinsics, rot0, loc0, lam, iters, quirks=QUIRKS_REFERENCE):

@@ -185,6 +185,56 @@ class HipCamposeMixin:
             ini_rot, ini_loc, damping_factor, iteration)
         return inlier_indices, ref_rot, ref_loc
 
+    # ---- two-view initialisation (campose_processor.py:29-189) --------------------------------------------
+    def extract_cam_pose_from_essential_mat(self, esse_mat):
+        """(r1, r2, c1, c2) of campose_processor.py:29-100.  The set {r1, r2} x {c1, c2} is the reference's;
+        which rotation is called r1 and which sign c1 carries follows LAPACK's singular-vector signs there and
+        the device's Jacobi sweep here (the caller tries all four combinations, ba_processor.py:81-97)."""
+        return native.pose_candidates(esse_mat)
+
+    def evalulate_cam_pose_cheirality(self, proj_1, proj_2, tri_3d_pts):
+        """Indices of the points in front of both cameras (campose_processor.py:133-189)."""
+        mask, _counts, _best = native.cheirality(proj_1, np.asarray(proj_2)[np.newaxis], np.asarray(tri_3d_pts)[np.newaxis])
+        return [int(i) for i in np.flatnonzero(mask[0])]
+
+    def disambiguate_cam_pose_four(self, ref_proj, projs_four, tri_3d_pts_four):
+        """(best_idx, most_valid_indices) of campose_processor.py:102-131: one device call for the four candidates."""
+        mask, counts, best = native.cheirality(ref_proj, np.array(projs_four), np.array(tri_3d_pts_four))
+        if counts[best] == 0:
+            return 0, []
+        return best, [int(i) for i in np.flatnonzero(mask[best])]
+
+
+class HipEpipolarMixin:
+    """Eight-point RANSAC and essential-matrix extraction of ``EpipolarProcessor`` (epipolar_processor.py:22-95)
+    on the device.  Expects ``self.ransac``; sets ``self.fund_mat`` / ``self.esse_mat`` as the reference does."""
+
+    def determine_fundamental_mat(self, matched_pairs, ransac_config=None):
+        import random
+        cfg = self.ransac if ransac_config is None else ransac_config
+        left, right = np.asarray(matched_pairs[0]), np.asarray(matched_pairs[1])
+        rows = left.shape[1]
+        if rows < 8:
+            logging.error('%s : number of matched pairs needs equal or more than eight')
+            raise ValueError("Insufficient matched pairs : {}".format(rows))
+        # same consumption of Python's global RNG stream as epipolar:225 (no draw when rows == 8)
+        samples = None if rows == 8 else [random.sample(range(rows), 8) for _ in range(cfg.iteration)]
+        fund, inliers, _best = native.fundamental_ransac(left, right, samples, cfg.inlier_threshold)
+        self.fund_mat = fund
+        return inliers
+
+    def extract_essential_mat(self, left_intrinsic_mat, right_intrinsic_mat):
+        self.esse_mat = native.essential_from_fundamental(self.fund_mat, left_intrinsic_mat, right_intrinsic_mat)
+
+
+class HipEpipolarProcessor(HipEpipolarMixin):
+    """Standalone EpipolarProcessor (constructor of epipolar_processor.py:13-20)."""
+
+    def __init__(self, ransac_config):
+        self.fund_mat = np.identity(3)
+        self.esse_mat = np.identity(3)
+        self.ransac = ransac_config
+
 
 class RansacConfig:
     """Mirror of utils.RansacConfig (utils.py:129-174): iteration count raised to the confidence bound and

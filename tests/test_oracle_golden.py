@@ -175,6 +175,43 @@ def test_g7_observation_list(oracle):
     assert [2, 7, 0] in got.tolist()
 
 
+def test_g8_fundamental(oracle):
+    """Eight-point RANSAC restatement vs the reference (epipolar_processor.py:22-267) on its unit-test literal
+    (epipolar:283-290), its epipolar_set text points and its opencv two-view pixel pairs."""
+    g = load_golden("g8_fundamental.npz")
+    lit = g["lit_pairs"]
+    inl, fund = oracle.determine_fundamental(lit[:, 0:2].T, lit[:, 2:4].T, None, 1e-3)
+    assert inl == list(range(8)) and np.array_equal(g["lit_inliers"], np.arange(8))
+    assert np.max(np.abs(fund - g["lit_fund"])) <= 1e-12 * np.max(np.abs(g["lit_fund"]))
+    for tag in ("eps", "ocv"):
+        pairs, tl, tr = oracle.fund_normalize(g[tag + "_left"], g[tag + "_right"])
+        assert np.max(np.abs(pairs - g[tag + "_pairs_norm"])) < 1e-13
+        assert np.max(np.abs(tl - g[tag + "_tl"])) < 1e-12 and np.max(np.abs(tr - g[tag + "_tr"])) < 1e-12
+        hyp = np.array([oracle.fund_eight_point(pairs[list(s)]) for s in g[tag + "_samples"][:24]])
+        assert np.max(np.abs(hyp - g[tag + "_f_hyp"]) / np.max(np.abs(g[tag + "_f_hyp"]), axis=(1, 2), keepdims=True)) < 1e-9
+        inl, fund = oracle.determine_fundamental(g[tag + "_left"], g[tag + "_right"], g[tag + "_samples"],
+                                                 float(g[tag + "_threshold"]))
+        assert inl == list(g[tag + "_inliers"])
+        assert np.max(np.abs(fund - g[tag + "_fund"])) <= 1e-11 * np.max(np.abs(g[tag + "_fund"]))
+    esse = oracle.essential_from_fundamental(g["ocv_fund"], g["ocv_K"], g["ocv_K"])
+    assert np.max(np.abs(esse - g["ocv_esse"])) <= 1e-12 * np.max(np.abs(g["ocv_esse"]))
+
+
+def test_g9_two_view_pose(oracle):
+    """Pose candidates, cheirality and disambiguation vs the reference on its own data files; the stored
+    OpenCV truth of campose_processor.py:838-851 within the reference's own 1e-2 bound (campose:878)."""
+    g = load_golden("g9_two_view_pose.npz")
+    r1, r2, c1, c2 = oracle.pose_candidates(g["esse"])
+    for got, want in ((r1, g["r1"]), (r2, g["r2"]), (c1, g["c1"]), (c2, g["c2"])):
+        assert np.max(np.abs(got - want)) < 1e-14
+    assert np.sum(np.abs(r1 - g["r1_truth"])) < 1e-2 and np.sum(np.abs(c2 - g["c2_truth"])) < 1e-2
+    best, valid = oracle.disambiguate(g["ref_proj"], list(g["projs"]), list(g["pts"]))
+    assert best == int(g["best"]) == 1                      # campose:934-937: R1T2 is the valid combination
+    assert valid == list(g["best_valid"])
+    counts = [len(oracle.cheirality(g["ref_proj"], g["projs"][i], g["pts"][i])) for i in range(4)]
+    assert counts == list(g["valid_counts"])
+
+
 def test_rmse_definition_matches_scene_helper(oracle, sfm):
     sc = sfm.scenes.make_scene(4, 60, 0.7, seed=3)
     a = oracle.rmse_pixels(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, sc.uv_pix, sc.intrinsic)
