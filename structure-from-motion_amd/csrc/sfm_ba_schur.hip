@@ -82,17 +82,6 @@ constexpr int NSTG = 4;            // ring of LDS stages (A panel + B panel each
 constexpr size_t kSchurLdsBytes = sizeof(double) * NSTG * 2 * STAGE;   // 147456 B
 static_assert(KSL == 16 && N_WAVES == 8, "schur_k_loop is written for 4 k-steps per slab and 2 DMA rows per wave and panel");
 
-// One wave-instruction = 64 lanes x 16 B = one 1 KiB panel row; the LDS destination is wave-uniform.
-__device__ __forceinline__ void stage_panel(const double* __restrict__ g /* &Zd[k0][128 * blk] */, size_t zp,
-                                            double* __restrict__ image, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < KSL / N_WAVES; ++i) {
-    const int r = wave + N_WAVES * i;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)r * zp + 2 * lane),
-                                     (__attribute__((address_space(3))) void*)(image + r * ZLD), 16, 0, 0);
-  }
-}
-
 // The k loop of one tile: a ring of NSTG LDS stages of KSL = 16 rows (4 MFMA k-steps), two operand register
 // sets.  Per slab s:
 //   k-step 0, 1      reads of the next k-step are issued BEFORE the MFMAs of the current one
@@ -111,8 +100,9 @@ template <bool DIAG, int NS, bool MMA, bool LOADS>
 __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, const double* __restrict__ pb, size_t zp,
                                              int k_beg, int nslab, double* __restrict__ img, const int (&oa)[5],
                                              const int (&ob)[5], int wr, int wc, double4_ (&acc)[8]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NA = DIAG ? NS : 4, NB = DIAG ? NS : 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: LDS-DMA destinations stay in SGPRs
+  constexpr int NA = DIAG ? NS : 4, NB = DIAG ? NS : 2, NM = DIAG ? NS : 8;
   constexpr int BATCH = (DIAG ? 1 : 2) * (KSL / N_WAVES);      // DMA instructions per wave and slab
   double a[2][NA], b[2][NB];
   const double* z0 = img + (lane >> 4) * ZLD + (lane & 15);
@@ -129,45 +119,63 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
   };
-  auto mma = [&](int set) {
-    if (MMA) {
-      if (DIAG) {
+  // Staging: one wave-instruction = 64 lanes x 16 B = one 1 KiB panel row, DMA'd to a wave-uniform LDS address.
+  // This wave owns rows (wave, wave + 8) of each panel; its global read pointers run along the k dimension.
+  const double* ga = pa + (size_t)(k_beg + wave) * zp + 2 * lane;
+  const double* gb = pb + (size_t)(k_beg + wave) * zp + 2 * lane;
+  const size_t row8 = 8 * zp, slab_step = (size_t)KSL * zp;
+  auto dma_piece = [&](int s, int j) {       // piece j of slab s: panel j >> 1, row wave + 8 * (j & 1)
+    if (!LOADS) return;
+    const double* g = ((j >> 1) ? gb : ga) + (j & 1) * row8;
+    double* l = img + ((s & (NSTG - 1)) * 2 + (j >> 1)) * STAGE + (wave + 8 * (j & 1)) * ZLD;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    if (j == BATCH - 1) { ga += slab_step; gb += slab_step; }
+  };
+  auto issue = [&](int s) {                  // slabs must be issued in order (running pointers)
 #pragma unroll
-        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][t], b[set][t], acc[t], 0, 0, 0);
-      } else {
+    for (int j = 0; j < BATCH; ++j) dma_piece(s, j);
+  };
+  // MFMAs of one k-step; dma_slab >= 0: the DMA pieces of that slab are issued one behind each of the first
+  // MFMAs, in the shadow of the matrix pipe, instead of ahead of them (where both waves of a SIMD spent the
+  // post-barrier cycles on address arithmetic with the pipe idle)
+  auto mma = [&](int set, int dma_slab) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-            acc[2 * x + y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][x], b[set][y], acc[2 * x + y], 0, 0, 0);
+    for (int i = 0; i < NM; ++i) {
+      if (MMA) {
+        if (DIAG) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i], b[set][i], acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[set][i >> 1], b[set][i & 1], acc[i], 0, 0, 0);
+      }
+      if (i < BATCH && dma_slab >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_piece(dma_slab, i);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // The operand reads issued before these MFMAs completed long ago (the wave spent >= 4 x 64 cycles issuing
+    // them): an explicit lgkmcnt(0) here is free and leaves no pending LDS read at the next load_ops, so the
+    // compiler's own wait before the following MFMAs covers nothing newer than it has to (without it it fell
+    // back to lgkmcnt(0) AFTER the next reads on the loop back-edge and behind the DMA block).
     __builtin_amdgcn_sched_barrier(0);
-  };
-  auto issue = [&](int s) {
-    if (!LOADS) return;
-    double* st = img + (s & (NSTG - 1)) * 2 * STAGE;
-    const size_t row = (size_t)(k_beg + s * KSL) * zp;
-    stage_panel(pa + row, zp, st, wave, lane);
-    if (!DIAG) stage_panel(pb + row, zp, st + STAGE, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
   };
   // one slab; the flags say whether slabs s+1, s+2, s+3 exist (compile-time, so the steady-state loop body is a
   // single basic block and the compiler's s_waitcnt placement stays exact)
   auto slab = [&](int s, auto has1, auto has2, auto has3) {
     load_ops(1, s, 4);
-    mma(0);
+    mma(0, -1);
     load_ops(0, s, 8);
-    mma(1);
+    mma(1, -1);
     if constexpr (decltype(has1)::value) {
       if constexpr (decltype(has2)::value) wait_vmcnt<BATCH>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if constexpr (decltype(has3)::value) issue(s + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
     load_ops(1, s, 12);
-    mma(0);
+    if constexpr (decltype(has3)::value) mma(0, s + 3); else mma(0, -1);
     if constexpr (decltype(has1)::value) load_ops(0, s + 1, 0);
-    mma(1);
+    mma(1, -1);
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -177,6 +185,8 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
   __builtin_amdgcn_s_barrier();
   if (nslab > 2) issue(2);
   load_ops(0, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // once per kernel: no LDS read is pending on either edge into the loop
+  __builtin_amdgcn_sched_barrier(0);
   int s = 0;
   for (; s + 3 < nslab; ++s) slab(s, T{}, T{}, T{});
   if (s + 2 < nslab) { slab(s, T{}, T{}, F{}); ++s; }
