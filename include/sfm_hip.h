@@ -45,10 +45,10 @@ extern "C" {
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
 #define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, pair kernel otherwise */
 #define SFM_SCHUR_PAIRS   1  /* per-point camera-pair kernel (f64 atomics) */
-#define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over zero-filled LDS tiles */
+#define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 2 no producer math, 4 no producer loads: results are wrong when set; 8 = record clock stamps) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps) */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */

@@ -9,7 +9,9 @@ library and fails loudly without it.
 Pinning: every function here is checked (tests/test_oracle_golden.py) against golden
 vectors captured by importing the real reference in the build container
 (tools/capture_goldens.py -> tests/golden/*.npz) and against the reference's own
-known-answer values (triangulation_processor.py:415-473, campose_processor.py:1073-1090).
+known-answer values (triangulation_processor.py:415-473, campose_processor.py:1073-1090,
+campose_processor.py:934; the two-view functions by g8/g9 from epipolar_processor.py and
+campose_processor.py:29-189 run on the reference's own data files).
 The reference has no test that pins bundle adjustment; BA is pinned by the captured
 goldens only.
 
