@@ -175,6 +175,17 @@ int sfm_ba_set_state(sfm_ba_problem* p, const double* cams /*[V][7]*/, const dou
 int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks);
 /* Synchronise, copy the state back, and report the first device-side failure (bad rotation ...). */
 int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
+/* Grow a resident problem in place — the incremental pipeline registers a view, triangulates new points and
+ * re-runs global BA (ba_processor.py:137-267).  n_new_cams cameras (indices V..)
+ * and n_new_pts points (indices N..) are appended with their initial state; n_new_obs observations of ANY
+ * (camera, point) pair not yet present are merged into the (point, camera)-sorted list.  The existing keys,
+ * cameras and points never leave the device: only the new data and the merged index structure are uploaded,
+ * a gather kernel rebuilds the key arrays, every workspace is re-planned for the new size.  The handle, its
+ * options and its current state survive; an externally bound reduced buffer must be bound again (its size
+ * follows V).  Blocking. */
+int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams /*[n_new_cams][7]*/, int n_new_pts,
+                  const double* pts /*[3][n_new_pts]*/, int64_t n_new_obs, const int* obs_cam /*[n_new_obs]*/,
+                  const int* obs_pt /*[n_new_obs]*/, const double* uv_norm /*[2][n_new_obs]*/);
 /* Accumulated device time of one kernel class since the last reset (needs SFM_OPT_TIMING = 1);
  * synchronises.  *launches may be NULL. */
 int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches);

@@ -92,6 +92,8 @@ struct sfm_ba_problem {
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
   bool schur_mfma_ok = false;
+  // host mirror of the static structure (sfm_ba_append merges new observations into it)
+  std::vector<int> h_pt_ptr, h_cam_idx;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 

@@ -836,6 +836,17 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   return SFM_OK;
 }
 
+// sfm_ba_append: keys of the merged observation list; src >= 0 = old observation, < 0 = new observation -1 - k
+__global__ void ba_append_gather_kernel(int m, const int* __restrict__ src, const double* __restrict__ u_old,
+                                        const double* __restrict__ v_old, const double* __restrict__ u_new,
+                                        const double* __restrict__ v_new, double* __restrict__ u, double* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int s = src[i];
+  if (s >= 0) { u[i] = u_old[s]; v[i] = v_old[s]; }
+  else { u[i] = u_new[-1 - s]; v[i] = v_new[-1 - s]; }
+}
+
 static int check_problem(const sfm_ba_problem* p) {
   if (p == nullptr || p->magic != kBaMagic) {
     set_error("invalid bundle-adjustment problem handle");
@@ -859,8 +870,9 @@ using namespace sfm;
 
 extern "C" {
 
-int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
-                  sfm_ba_problem** out) {
+// uv_norm == nullptr: the keys are filled on the device afterwards (sfm_ba_append)
+static int ba_create_impl(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                          sfm_ba_problem** out) {
   SFM_TRY(ensure_init());
   if (out == nullptr) { set_error("sfm_ba_create: out is null"); return SFM_E_SHAPE; }
   *out = nullptr;
@@ -915,15 +927,26 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
   if (M > 0) {
     if (hipMemcpyAsync(d.cam_idx, cam_idx, sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
     if (hipMemcpyAsync(d.obs_pt, obs_pt.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-    if (hipMemcpyAsync(d.u, uv_norm, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-    if (hipMemcpyAsync(d.v, uv_norm + M, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+    if (uv_norm) {
+      if (hipMemcpyAsync(d.u, uv_norm, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+      if (hipMemcpyAsync(d.v, uv_norm + M, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
+    }
   }
+  p->h_pt_ptr.assign(pt_ptr, pt_ptr + (N > 0 ? N + 1 : 0));
+  if (N == 0) p->h_pt_ptr.assign(1, 0);
+  p->h_cam_idx.assign(cam_idx, cam_idx + M);
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, s) != hipSuccess) return fail(SFM_E_HIP);
   if (hipStreamSynchronize(s) != hipSuccess) return fail(SFM_E_HIP);
   { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
   return SFM_OK;
+}
+
+int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                  sfm_ba_problem** out) {
+  if (M > 0 && uv_norm == nullptr) { set_error("sfm_ba_create: uv_norm is null"); return SFM_E_SHAPE; }
+  return ba_create_impl(V, N, M, pt_ptr, cam_idx, uv_norm, out);
 }
 
 int sfm_ba_destroy(sfm_ba_problem* p) {
@@ -1019,6 +1042,95 @@ int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
     return st[0];
   }
   return SFM_OK;
+}
+
+int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int n_new_pts, const double* pts_new,
+                  int64_t n_new_obs, const int* obs_cam, const int* obs_pt, const double* uv_norm) {
+  SFM_TRY(check_problem(p));
+  if (n_new_cams < 0 || n_new_pts < 0 || n_new_obs < 0) { set_error("sfm_ba_append: negative count"); return SFM_E_SHAPE; }
+  BaDev& d = p->dev;
+  const int V2 = d.V + n_new_cams, N2 = d.N + n_new_pts;
+  const long long M2 = d.M + n_new_obs;
+  if (M2 > 0x7fffffffLL) { set_error("sfm_ba_append: too many observations"); return SFM_E_SHAPE; }
+  for (long long k = 0; k < n_new_obs; ++k)
+    if (obs_cam[k] < 0 || obs_cam[k] >= V2 || obs_pt[k] < 0 || obs_pt[k] >= N2) {
+      set_error("sfm_ba_append: observation %lld = (camera %d, point %d) out of range", k, obs_cam[k], obs_pt[k]);
+      return SFM_E_SHAPE;
+    }
+  // merged structure on the host: per point the old (sorted) camera list and the new observations, by camera.
+  // src[o'] >= 0: old observation index; < 0: new observation -1 - k.
+  std::vector<int> cnt((size_t)N2 + 1, 0), new_ptr((size_t)N2 + 1, 0);
+  for (long long k = 0; k < n_new_obs; ++k) cnt[obs_pt[k]]++;
+  std::vector<int> nstart((size_t)N2 + 1, 0);
+  for (int q = 0; q < N2; ++q) nstart[q + 1] = nstart[q] + cnt[q];
+  std::vector<int> norder((size_t)n_new_obs), fill(nstart.begin(), nstart.end() - 1);
+  for (long long k = 0; k < n_new_obs; ++k) norder[fill[obs_pt[k]]++] = (int)k;
+  std::vector<int> cam2((size_t)M2), src((size_t)M2);
+  int max_k = 0;
+  long long w = 0;
+  for (int q = 0; q < N2; ++q) {
+    new_ptr[q] = (int)w;
+    int* nb = norder.data() + nstart[q];
+    int* ne = norder.data() + nstart[q + 1];
+    std::sort(nb, ne, [&](int a, int b) { return obs_cam[a] < obs_cam[b]; });
+    int o = q < d.N ? p->h_pt_ptr[q] : 0;
+    const int oe = q < d.N ? p->h_pt_ptr[q + 1] : 0;
+    while (o < oe || nb < ne) {
+      const int co = o < oe ? p->h_cam_idx[o] : 0x7fffffff;
+      const int cn = nb < ne ? obs_cam[*nb] : 0x7fffffff;
+      if (co == cn || (w > new_ptr[q] && std::min(co, cn) == cam2[w - 1])) {
+        set_error("sfm_ba_append: point %d is already observed by camera %d", q, std::min(co, cn));
+        return SFM_E_SHAPE;
+      }
+      if (co < cn) { cam2[w] = co; src[w] = o++; }
+      else { cam2[w] = cn; src[w] = -1 - *nb++; }
+      ++w;
+    }
+    max_k = std::max(max_k, (int)(w - new_ptr[q]));
+  }
+  new_ptr[N2] = (int)w;
+  (void)max_k;
+  sfm_ba_problem* q = nullptr;
+  SFM_TRY(ba_create_impl(V2, N2, M2, new_ptr.data(), cam2.data(), nullptr, &q));
+  auto fail = [&](int st) { sfm_ba_destroy(q); return st; };
+  hipStream_t s = ctx().stream;
+  BaDev& e = q->dev;
+  {
+    DevBuf<int> dsrc;
+    DevBuf<double> duv;
+    int st = dsrc.upload(src.data(), (size_t)M2, s);
+    if (st == SFM_OK) st = n_new_obs > 0 ? duv.upload(uv_norm, 2 * (size_t)n_new_obs, s) : duv.alloc(2);
+    if (st != SFM_OK) return fail(st);
+    if (M2 > 0) {
+      ba_append_gather_kernel<<<(unsigned)((M2 + 255) / 256), 256, 0, s>>>((int)M2, dsrc.p, d.u, d.v, duv.p, duv.p + n_new_obs, e.u, e.v);
+      if (hipGetLastError() != hipSuccess) return fail(SFM_E_HIP);
+    }
+    // state: old cameras / points stay on the device, the new ones are uploaded behind them
+    bool ok = hipMemcpyAsync(e.cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (n_new_cams > 0) ok = ok && hipMemcpyAsync(e.cams + 7 * (size_t)d.V, cams_new, sizeof(double) * 7 * n_new_cams, hipMemcpyHostToDevice, s) == hipSuccess;
+    double* dst[3] = {e.px, e.py, e.pz};
+    const double* old[3] = {d.px, d.py, d.pz};
+    for (int k = 0; k < 3; ++k) {
+      if (d.N > 0) ok = ok && hipMemcpyAsync(dst[k], old[k], sizeof(double) * d.N, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      if (n_new_pts > 0) ok = ok && hipMemcpyAsync(dst[k] + d.N, pts_new + (size_t)k * n_new_pts, sizeof(double) * n_new_pts, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) return fail(SFM_E_HIP);
+  }
+  // the handle keeps its identity and options; the old buffers leave with q
+  q->schur_mode = p->schur_mode; q->debug = p->debug; q->timing = p->timing; q->quirks = p->quirks;
+  std::swap(p->dev, q->dev);
+  std::swap(p->own_red, q->own_red);
+  std::swap(p->schur_ws, q->schur_ws);
+  std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
+  std::swap(p->max_track, q->max_track);
+  p->h_pt_ptr.swap(q->h_pt_ptr);
+  p->h_cam_idx.swap(q->h_cam_idx);
+  p->dev.red = p->own_red;          // a bound external reduced buffer has the wrong size now: rebind after append
+  q->dev.red = q->own_red;
+  p->cur = 0; p->prep_valid = false; p->red_clean = false; p->lin_rows = 0;
+  std::swap(p->dev.stamps, q->dev.stamps);      // the diagnostic stamp buffer stays with the handle
+  return sfm_ba_destroy(q);
 }
 
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {

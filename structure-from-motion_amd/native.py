@@ -29,7 +29,7 @@ EXPORTS = (
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
-    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
+    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
 )
@@ -388,6 +388,22 @@ class BaProblem:
         cams = np.empty((self.n_cams, 7)); pts = np.empty((3, self.n_pts))
         check(self._lib.sfm_ba_get_state(self._h, dptr(cams), dptr(pts)))
         return cams, pts
+
+    def append(self, cams_new, pts_new, obs_cam, obs_pt, uv_norm):
+        """Grow the resident scene (sfm_ba_append): new cameras (k,7), new points (3,k), new observations
+        (camera index, point index, normalised key (2,m)) of pairs not yet present; nothing already on the
+        device is uploaded again."""
+        cams_new = f64(cams_new).reshape(-1, 7); pts_new = f64(pts_new).reshape(3, -1)
+        obs_cam = i32(obs_cam).ravel(); obs_pt = i32(obs_pt).ravel(); uv_norm = f64(uv_norm).reshape(2, -1)
+        if not (obs_cam.shape[0] == obs_pt.shape[0] == uv_norm.shape[1]):
+            raise ValueError("append: obs_cam, obs_pt and uv_norm disagree in length")
+        self._lib.sfm_ba_append.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64,
+                                            _ip, _ip, _dp]
+        check(self._lib.sfm_ba_append(self._h, cams_new.shape[0], dptr(cams_new), pts_new.shape[1], dptr(pts_new),
+                                      obs_cam.shape[0], iptr(obs_cam), iptr(obs_pt), dptr(uv_norm)))
+        self.n_cams += cams_new.shape[0]
+        self.n_pts += pts_new.shape[1]
+        self.n_obs += obs_cam.shape[0]
 
     def reduced_buffer(self):
         ptr = ctypes.c_void_p(); n = ctypes.c_int64(); ld = ctypes.c_int()
