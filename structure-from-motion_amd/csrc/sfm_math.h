@@ -148,44 +148,6 @@ SFM_HD void jac_cam(const CamPrep& c, double X, double Y, double Z, const double
   jac_cam_iz(c, X, Y, Z, p, 1.0 / p[2], quirks, Jp);
 }
 
-// The same Jacobian as the literal product J_R (2x9) @ J_q (9x4) of the reference (campose:742-766, 654-700).
-// Kept beside the factored form: in the Schur producers, where the FP64 pipe is shared with MFMA, this
-// shape measured faster (profiles/r02g A/B), while the factored form wins in the streaming kernels.
-SFM_HD void jac_cam_table(const CamPrep& c, double X, double Y, double Z, const double* p, int quirks,
-                          double* Jp) {
-  const double* R = c.R;
-  const double px = p[0], py = p[1], pz = p[2];
-  const double iz2 = 1.0 / (pz * pz);
-  const double d[3] = {X - c.C[0], Y - c.C[1], Z - c.C[2]};
-  const double sgn = (quirks & SFM_Q2_LOC_JAC_SIGN) ? 1.0 : -1.0;
-  for (int i = 0; i < 3; ++i) {
-    Jp[i] = (pz * -R[3 * i + 0] - px * -R[3 * i + 2]) * iz2;
-    Jp[7 + i] = (pz * -R[3 * i + 1] - py * (sgn * R[3 * i + 2])) * iz2;
-  }
-  double a[3], bu[3], bv[3];
-  for (int i = 0; i < 3; ++i) {
-    a[i] = pz * d[i] * iz2;
-    bu[i] = -px * d[i] * iz2;
-    bv[i] = -py * d[i] * iz2;
-  }
-  const double w2 = 2 * c.q[0], x2 = 2 * c.q[1], y2 = 2 * c.q[2], z2 = 2 * c.q[3];
-  const double x4 = 4 * c.q[1], y4 = 4 * c.q[2], z4 = 4 * c.q[3];
-  const double jq[9][4] = {{0, 0, -y4, -z4},   {-z2, y2, x2, -w2}, {y2, z2, w2, x2},
-                           {z2, y2, x2, w2},   {0, -x4, 0, -z4},   {-x2, -w2, z2, y2},
-                           {-y2, z2, -w2, x2}, {x2, w2, z2, y2},   {0, -x4, -y4, 0}};
-  for (int k = 0; k < 4; ++k) {
-    double su = 0, sv = 0;
-    for (int i = 0; i < 3; ++i) {
-      su += a[i] * jq[3 * i + 0][k];
-      sv += a[i] * jq[3 * i + 1][k];
-      su += bu[i] * jq[3 * i + 2][k];
-      sv += bv[i] * jq[3 * i + 2][k];
-    }
-    Jp[3 + k] = su;
-    Jp[7 + 3 + k] = sv;
-  }
-}
-
 // Jx (2x3, row-major) for a general 3x4 projection P (row-major P[4*i+j]) and s = P @ X~
 // (triangulation_processor.py:261-269).
 SFM_HD void jac_pt(const double* P, const double* s, double* Jx) {
@@ -204,33 +166,6 @@ SFM_HD void jac_pt_cam_iz(const CamPrep& c, const double* p, double iz, double* 
     Jx[j] = (p[2] * R[3 * j + 0] - p[0] * R[3 * j + 2]) * iz2;
     Jx[3 + j] = (p[2] * R[3 * j + 1] - p[1] * R[3 * j + 2]) * iz2;
   }
-}
-
-SFM_HD void jac_pt_cam(const CamPrep& c, const double* p, double* Jx) {
-  const double* R = c.R;
-  const double iz2 = 1.0 / (p[2] * p[2]);     // shares its division with jac_cam_table
-  for (int j = 0; j < 3; ++j) {
-    Jx[j] = (p[2] * R[3 * j + 0] - p[0] * R[3 * j + 2]) * iz2;
-    Jx[3 + j] = (p[2] * R[3 * j + 1] - p[1] * R[3 * j + 2]) * iz2;
-  }
-}
-
-// Cholesky of a symmetric 3x3 (a00,a10,a11,a20,a21,a22) -> inverse factor Li (lower, row-major
-// packed l00,l10,l11,l20,l21,l22) with Li = L^-1, so that A^-1 = Li^T Li.
-SFM_HD void chol3_inv(const double* a, double* li) {
-  const double l00 = sqrt(a[0]);
-  const double l10 = a[1] / l00;
-  const double l11 = sqrt(a[2] - l10 * l10);
-  const double l20 = a[3] / l00;
-  const double l21 = (a[4] - l20 * l10) / l11;
-  const double l22 = sqrt(a[5] - l20 * l20 - l21 * l21);
-  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
-  li[0] = i00;
-  li[1] = -l10 * i00 * i11;
-  li[2] = i11;
-  li[3] = (-l20 * i00 - l21 * li[1]) * i22;
-  li[4] = -l21 * i11 * i22;
-  li[5] = i22;
 }
 
 }  // namespace sfm
