@@ -32,7 +32,7 @@ struct BaDev {
   double* pz = nullptr;
   // per-iteration scratch
   CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
-  double* Z = nullptr;      // [21][M] (SoA)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j; pair-kernel path only (lazy)
+  double* Z = nullptr;      // [M][21] (AoS)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j; sparse-product path only (lazy)
   double* Zd = nullptr;     // [zrows][zp] dense Z^T for the MFMA product: row 3p + j, column 128*(cam/18) + 7*(cam%18) + i;
                             // entries of invisible (point, camera) pairs and all padding stay zero for the problem's lifetime
   int zp = 0;               // row pitch of Zd = 128 * ceil(V / 18)
@@ -91,6 +91,7 @@ struct sfm_ba_problem {
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
+  int* schur_blk_ptr = nullptr;  // [N][nblk + 1] first observation of a point in each 18-camera block (sparse path)
   bool schur_mfma_ok = false;
   // host mirror of the static structure (sfm_ba_append merges new observations into it)
   std::vector<int> h_pt_ptr, h_cam_idx;

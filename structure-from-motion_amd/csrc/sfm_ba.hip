@@ -164,13 +164,17 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
             row[6] = zz[6];
           }
         } else {
-          double* zo = d.Z + o;                       // SoA: element e of observation o at Z[e * M + o]
-          const size_t zs = (size_t)d.M;
+          double* zo = d.Z + (size_t)o * 21;          // AoS: the 21 elements of observation o are contiguous
+          typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+          double zz[22];
 #pragma unroll
           for (int i = 0; i < 7; ++i) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) zo[(3 * i + j) * zs] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
+            for (int j = 0; j < 3; ++j) zz[3 * i + j] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
           }
+#pragma unroll
+          for (int e = 0; e < 20; e += 2) *reinterpret_cast<d2u*>(zo + e) = d2u{zz[e], zz[e + 1]};
+          zo[20] = zz[20];
         }
       }
       // rhs_c -= W V^-1 g = Jp^T (Jx h) with h = V^-1 g: folded into the residual, e = r - Jx h
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
   }
   if (stamp && sidx < 62) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   if (ACC_LDS) {
-    // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_cam_reduce_kernel adds
+    // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_schur_reduce_kernel adds
     // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
     // addresses: ~18 G atomics/s on MI355X, 50 us at C3.)
     __syncthreads();
@@ -205,13 +209,6 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) row[t] = lds_acc[t];
   }
   if (stamp && sidx < 63) { stamp[sidx++] = __builtin_amdgcn_s_memtime(); stamp[63] = sidx; }
-}
-
-// Sum the per-workgroup camera accumulators of ba_linearize into the diagonal blocks of S (lower
-// part) and rhs.  grid = (ceil(35 V / 256), 48): slice g adds its share of the workspace rows and
-// finishes with one f64 atomic per element (48-way instead of 768-way contention).
-__global__ __launch_bounds__(256) void ba_cam_reduce_kernel(BaDev d, int nrows) {
-  cam_reduce_slice(d, nrows, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, gridDim.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,7 +766,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   p->quirks = quirks;
   const bool dense_z = ba_schur_uses_mfma(p);
   if (dense_z) SFM_TRY(ba_schur_prepare_dense(p, s));
-  if (!dense_z && d.Z == nullptr && d.M > 0) {     // pair-kernel path: Z as SoA [21][M] (168 B/obs)
+  if (!dense_z && d.Z == nullptr && d.M > 0) {     // sparse-product path: Z as AoS [M][21] (168 B/obs)
     SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.Z), sizeof(double) * 21 * (size_t)d.M));
   }
   const size_t lds_acc = sizeof(double) * (size_t)d.V * 35;
@@ -785,10 +782,6 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
     else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
   }
   p->lin_rows = mode >= 1 ? grid : 0;
-  if (mode >= 1 && !dense_z) {         // pair path: own launch; the MFMA path folds this sum into ba_schur_reduce_kernel
-    dim3 rgrid((d.V * 35 + 255) / 256, 48);
-    ba_cam_reduce_kernel<<<rgrid, 256, 0, s>>>(d, grid);
-  }
   tick(p, SFM_K_LINEARIZE, false, s);
   SFM_HIP(hipGetLastError());
   tick(p, SFM_K_SCHUR, true, s);
@@ -955,7 +948,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws};
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws, p->schur_blk_ptr};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1122,6 +1115,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   std::swap(p->dev, q->dev);
   std::swap(p->own_red, q->own_red);
   std::swap(p->schur_ws, q->schur_ws);
+  std::swap(p->schur_blk_ptr, q->schur_blk_ptr);
   std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
   std::swap(p->max_track, q->max_track);
   p->h_pt_ptr.swap(q->h_pt_ptr);

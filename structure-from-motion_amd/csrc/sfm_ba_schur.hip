@@ -2,51 +2,21 @@
 // ba_processor.py:382, in the symmetric form Z_o = W_o L_p^-T).  Only the lower triangle of S
 // (row >= column) is produced; block (c_a, c_b) with c_a > c_b of point p is Z_a Z_b^T.
 //
-//   ba_schur_pairs_kernel   one wave per point: the point's Z rows staged in LDS, every camera pair
-//                           (a >= b) x 49 entries as lane tasks, f64 atomics into S.  Work is
-//                           proportional to sum_p k_p (k_p+1)/2 (sparse-optimal); bound by the f64
-//                           atomic rate.  Used for small or sparse scenes.
+//   ba_schur_pairs_kernel   sparse: (18-camera tile) x (point chunk) workgroups, the tile accumulated in LDS
+//                           with ds_add_f64, only camera pairs that share a point are multiplied.  Work is
+//                           proportional to sum_p k_p (k_p+1)/2 (sparse-optimal).  Used at low visibility.
 //   ba_schur_mfma_kernel    dense  v_mfma_f64_16x16x4_f64  SYRK  S -= Zd^T Zd  over the dense matrix Zd
 //                           that ba_linearize fills (zeros where a point is not seen); panels are DMA'd
 //                           HBM -> LDS (global_load_lds); output-stationary 128x128 tiles x split-K row
 //                           chunks; no atomics.  Used when visibility is high enough that dense wins.
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 #include <vector>
 
 #include "sfm_ba.h"
 
 namespace sfm {
-
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ba_schur_pairs_kernel(BaDev d) {
-  extern __shared__ double zl[];            // [max_track][21]
-  double* S = d.red;
-  const int lane = threadIdx.x;
-  for (int p = blockIdx.x; p < d.N; p += gridDim.x) {
-    const int beg = d.pt_ptr[p], k = d.pt_ptr[p + 1] - beg;
-    for (int t = lane; t < k * 21; t += 64) {      // Z is SoA [21][M]; LDS image is [track slot][21]
-      const int e = t / k, a = t - e * k;
-      zl[a * 21 + e] = d.Z[(size_t)e * d.M + beg + a];
-    }
-    __syncthreads();
-    for (int a = 0; a < k; ++a) {
-      const int ca = d.cam_idx[beg + a];
-      const double* za = zl + a * 21;
-      const int ntask = (a + 1) * 49;
-      for (int t = lane; t < ntask; t += 64) {
-        const int b = t / 49, e = t - b * 49;
-        const int i = e / 7, j = e - i * 7;
-        if (b == a && j > i) continue;                   // diagonal block: lower part only
-        const double* zb = zl + b * 21;
-        const double val = za[3 * i] * zb[3 * j] + za[3 * i + 1] * zb[3 * j + 1] + za[3 * i + 2] * zb[3 * j + 2];
-        const int cb = d.cam_idx[beg + b];
-        atomicAdd(&S[(size_t)(7 * ca + i) * d.ld + 7 * cb + j], -val);
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Dense MFMA product  S(lower) -= Zd^T Zd  over the materialised Z.
@@ -273,6 +243,138 @@ struct SchurPlan {
   int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
 };
 
+// ---------------------------------------------------------------------------------------------
+// Sparse product (low visibility): the same 18-camera blocks and split-K slabs as the dense path, but a tile's
+// 126x126 accumulator lives in LDS and only the camera pairs that actually share a point are multiplied.
+// One workgroup = (tile (A, B), chunk of points), 16 waves; a wave takes a point, finds its observations in
+// block A and in block B through the per-point block offsets (blk_ptr, built at plan time; the observations
+// of a point are sorted by camera, so a block is a contiguous sub-range) and multiplies their Z blocks (AoS,
+// 168 B each, read straight from L2); every product is one ds_add_f64 into the tile.  No global atomics: the
+// tile goes to its slab and ba_schur_reduce sums the
+// slabs exactly as for the dense path.  Work is proportional to sum_p k_p (k_p + 1) / 2 (sparse-optimal).
+// ---------------------------------------------------------------------------------------------
+constexpr int PAIR_WAVES = 16;                      // the per-visit work is tiny at low visibility: occupancy hides it
+constexpr int PAIR_THREADS = 64 * PAIR_WAVES;
+constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubles)
+constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP;
+
+// One (point, tile) visit by one wave.  Lanes = (observation b of block B, column j): each keeps its three
+// Z values and its tile column in registers.  The A side is loaded in ONE batch: register slot a of lanes
+// 0..20 holds the 21 values of observation a (all <= 18 loads in flight together, a single memory latency per
+// visit instead of one per observation); the wave then walks the slots, reads row i's three values with
+// v_readlane (constant lane, constant slot) and issues one ds_add_f64 per lane and row.  The block offsets of
+// the wave's NEXT point are fetched before the current visit is computed.
+__device__ __forceinline__ double lane_value(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __restrict__ blk_ptr, int nblk, int ti, int tj,
+                                                int p_beg, int p_end, double* __restrict__ slab, double* __restrict__ tile) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int t = tid; t < 7 * CB * TP; t += PAIR_THREADS) tile[t] = 0.0;
+  __syncthreads();
+  const double* __restrict__ Z = d.Z;
+  const int* __restrict__ cam_idx = d.cam_idx;
+  // lanes 0..3 fetch bp[ti], bp[ti+1], bp[tj], bp[tj+1] of a point
+  auto fetch_bp = [&](int p) -> int {
+    if (p >= p_end) return 0;
+    const int which = lane & 3;
+    return blk_ptr[(size_t)p * (nblk + 1) + ((which & 2) ? tj : ti) + (which & 1)];
+  };
+  // Three-deep software pipeline over this wave's points: block offsets two visits ahead, the visit's Z blocks
+  // and camera slots one visit ahead, products now -- the memory latency of a visit hides behind the previous one.
+  struct Visit {
+    int a0, kA, b0, kB;
+    double za[CB];             // slot a, lanes 0..20: Z block of observation a0 + a
+    int ca_lane;               // lanes 0..kA-1: tile row offset of camera slot a
+    double zb0, zb1, zb2;      // first lane round of the B side
+    int col;                   // its tile column (or -1)
+  };
+  auto load_visit = [&](int bp, Visit& v) {
+    v.a0 = __builtin_amdgcn_readlane(bp, 0); v.kA = __builtin_amdgcn_readlane(bp, 1) - v.a0;
+    v.b0 = __builtin_amdgcn_readlane(bp, 2); v.kB = __builtin_amdgcn_readlane(bp, 3) - v.b0;
+    if (v.kA <= 0 || v.kB <= 0) { v.kA = 0; return; }
+    const int zl = lane < 21 ? lane : 20;
+#pragma unroll
+    for (int a = 0; a < CB; ++a) v.za[a] = (a < v.kA) ? Z[(size_t)(v.a0 + a) * 21 + zl] : 0.0;
+    v.ca_lane = 7 * TP * (cam_idx[v.a0 + (lane < v.kA ? lane : 0)] - ti * CB);
+    const bool on = lane < 7 * v.kB;
+    const int b = on ? lane / 7 : 0, j = lane - 7 * b;
+    const double* zb = Z + (size_t)(v.b0 + b) * 21 + 3 * j;
+    v.zb0 = zb[0]; v.zb1 = zb[1]; v.zb2 = zb[2];
+    v.col = on ? 7 * (cam_idx[v.b0 + b] - tj * CB) + j : -1;
+  };
+  auto products = [&](const Visit& v, int b, double zb0, double zb1, double zb2, int col) {
+    double* tcol = tile + col;
+#pragma unroll
+    for (int a = 0; a < CB; ++a) {
+      if (a < v.kA) {                                      // wave-uniform
+        double* trow = tcol + __builtin_amdgcn_readlane(v.ca_lane, a);
+        const bool mine = col >= 0 && (!DIAG || b <= a);   // lower part of a diagonal tile only
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const double val = lane_value(v.za[a], 3 * i) * zb0 + lane_value(v.za[a], 3 * i + 1) * zb1 + lane_value(v.za[a], 3 * i + 2) * zb2;
+          if (mine) atomicAdd(trow + i * TP, val);
+        }
+      }
+    }
+  };
+  Visit cur, nxt;
+  cur.kA = 0; nxt.kA = 0;
+  int p = p_beg + wave;
+  int bp1 = fetch_bp(p);                        // offsets of visit p
+  if (p < p_end) load_visit(bp1, cur);
+  int bp2 = fetch_bp(p + PAIR_WAVES);           // offsets of visit p + 16
+  for (; p < p_end; p += PAIR_WAVES) {
+    const int bp3 = fetch_bp(p + 2 * PAIR_WAVES);
+    nxt.kA = 0;
+    if (p + PAIR_WAVES < p_end) load_visit(bp2, nxt);
+    if (cur.kA > 0) {
+      products(cur, lane / 7, cur.zb0, cur.zb1, cur.zb2, cur.col);
+      if (7 * cur.kB > 64) {                    // second lane round (more than 9 observations in block B)
+        const int l = 64 + lane;
+        const bool on = l < 7 * cur.kB;
+        const int b = on ? l / 7 : 0, j = l - 7 * b;
+        const double* zb = Z + (size_t)(cur.b0 + b) * 21 + 3 * j;
+        products(cur, b, zb[0], zb[1], zb[2], on ? 7 * (cam_idx[cur.b0 + b] - tj * CB) + j : -1);
+      }
+    }
+    cur = nxt;
+    bp2 = bp3;
+  }
+  __syncthreads();
+  for (int t = tid; t < 7 * CB * 7 * CB; t += PAIR_THREADS) {
+    const int r = t / (7 * CB), c = t - r * (7 * CB);
+    slab[r * RB + c] = tile[r * TP + c];
+  }
+}
+
+__global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, const int* __restrict__ blk_ptr,
+                                                                     double* __restrict__ ws, SchurPlan plan) {
+  extern __shared__ double lds_pairs[];
+  double* tile = lds_pairs;
+  const int w = blockIdx.x;
+  const int off_wgs = plan.n_off * plan.chunks_off;
+  double* slab = ws + (size_t)w * (RB * RB);
+  if (w < off_wgs) {
+    int t = w / plan.chunks_off, ti = 1;
+    const int chunk = w - t * plan.chunks_off;
+    while (t >= ti) { t -= ti; ++ti; }
+    const int p_beg = chunk * plan.rpc_off;
+    pairs_tile_body<false>(d, blk_ptr, plan.nblk, ti, t, p_beg, min(d.N, p_beg + plan.rpc_off), slab, tile);
+  } else {
+    const int w2 = w - off_wgs;
+    const int ti = w2 / plan.chunks_diag;
+    const int chunk = w2 - ti * plan.chunks_diag;
+    const int p_beg = chunk * plan.rpc_diag;
+    pairs_tile_body<true>(d, blk_ptr, plan.nblk, ti, ti, p_beg, min(d.N, p_beg + plan.rpc_diag), slab, tile);
+  }
+}
+
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
   extern __shared__ double img[];               // [NSTG stages][A panel, B panel][KSL][ZLD]
   const int w = blockIdx.x;
@@ -366,23 +468,60 @@ static SchurPlan make_plan(const BaDev& d) {
   return pl;
 }
 
-// Plan of the MFMA product: shape of Zd, chunking of its rows and the split-K slab workspace.  Zd itself is
-// allocated (and zero-filled) on first use by ba_schur_prepare_dense.
+// Work split of the sparse product: every tile gets the same number of point chunks, about two workgroups per
+// CU in total (one is resident per CU: 128 KB of LDS, 16 waves), at least 64 points per chunk.
+static SchurPlan make_pairs_plan(const BaDev& d) {
+  SchurPlan pl;
+  pl.dbg = 0;
+  pl.nblk = (d.V + CB - 1) / CB;
+  pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
+  const int ntiles = pl.n_off + pl.nblk;
+  int chunks = std::max(1, 2 * ctx().num_cus / ntiles);
+  chunks = std::max(1, std::min(chunks, (d.N + 63) / 64));
+  const int ppc = (d.N + chunks - 1) / chunks;
+  chunks = (d.N + ppc - 1) / std::max(1, ppc);
+  pl.chunks_off = pl.n_off ? chunks : 0;
+  pl.chunks_diag = chunks;
+  pl.rpc_off = pl.rpc_diag = std::max(1, ppc);
+  return pl;
+}
+
+// Plans of both products: block offsets of every point (sparse path), shape of Zd and chunking of its rows
+// (dense path), and the split-K slab workspace both share.  Zd itself is allocated (and zero-filled) on first
+// use by ba_schur_prepare_dense.
 int ba_schur_plan(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   d.zp = RB * ((d.V + CB - 1) / CB);
   d.zrows = ((3 * d.N + KSL - 1) / KSL) * KSL;
   const SchurPlan pl = make_plan(d);
+  const SchurPlan pp = make_pairs_plan(d);
   const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
-  const size_t ws_bytes = sizeof(double) * (size_t)wgs * RB * RB;
+  const int wgs_pairs = pp.n_off * pp.chunks_off + pp.nblk * pp.chunks_diag;
+  const size_t ws_dense = sizeof(double) * (size_t)wgs * RB * RB;
+  const size_t ws_pairs = sizeof(double) * (size_t)wgs_pairs * RB * RB;
   const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
   // the dense path is only ever chosen when it is cheaper than the pair path; do not reserve
   // tens of gigabytes for scenes that will never take it
-  p->schur_mfma_ok = d.N > 0 && ws_bytes + zd_bytes <= ((size_t)32 << 30);
-  if (!p->schur_mfma_ok) return SFM_OK;
-  SFM_HIP(pool_alloc(&p->schur_ws, ws_bytes));
+  p->schur_mfma_ok = d.N > 0 && ws_dense + zd_bytes <= ((size_t)32 << 30);
+  SFM_HIP(pool_alloc(&p->schur_ws, std::max(p->schur_mfma_ok ? ws_dense : 0, ws_pairs)));
+  // per-point block offsets: blk_ptr[p][b] = first observation of point p whose camera is >= 18 b
+  const int nb1 = pp.nblk + 1;
+  std::vector<int> bp((size_t)std::max(1, d.N) * nb1, 0);
+  for (int q = 0; q < d.N; ++q) {
+    int o = p->h_pt_ptr[q];
+    const int oe = p->h_pt_ptr[q + 1];
+    for (int b = 0; b < nb1; ++b) {
+      while (o < oe && p->h_cam_idx[o] < b * CB) ++o;
+      bp[(size_t)q * nb1 + b] = o;
+    }
+    bp[(size_t)q * nb1 + pp.nblk] = oe;
+  }
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_blk_ptr), sizeof(int) * bp.size()));
+  SFM_HIP(hipMemcpy(p->schur_blk_ptr, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
+  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes));
   return SFM_OK;
 }
 
@@ -403,36 +542,39 @@ bool ba_schur_uses_mfma(const sfm_ba_problem* p) {
   if (p->schur_mode == SFM_SCHUR_PAIRS) return false;
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return false;
-  // Measured on MI355X at C3 (profiles/r01p): the dense product retires ~22 T MACs/s of its (7V)^2/2 * 3N
-  // MACs, the pair kernel ~0.08 T f64 atomic adds/s of its 49 * sum k(k+1)/2 adds: one add costs ~280 MACs.
-  const double dense = 0.5 * (double)d.P * d.P * 3.0 * d.N;
+  // Cost models fitted on MI355X (profiles/r02i): the dense SYRK retires ~29 T MAC/s of its
+  // (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs; the sparse kernel costs ~0.5 ns per
+  // (point, tile) visit plus ~0.7 ps per LDS add (C3: 120 k visits, 456 M adds -> 0.38 ms; a 12.5 k-point
+  // 200-camera shard at 15 %: 975 k visits, 285 M adds -> 0.65 ms against 1.58 ms dense).
+  const double nblk = (double)((d.V + CB - 1) / CB);
   const double kbar = (double)d.M / d.N;
-  const double pairs = 49.0 * 0.5 * kbar * (kbar + 1) * d.N;
-  return dense < 250.0 * pairs;
+  const double dense_s = (0.5 * nblk * (nblk - 1) * 64.0 + nblk * 36.0) * 256.0 * 3.0 * d.N / 29e12 + 15e-6;
+  const double nocc = nblk * (1.0 - std::pow(1.0 - 1.0 / nblk, kbar));            // occupied blocks per point
+  const double visits = 0.5 * nocc * (nocc + 1.0) * d.N;
+  const double adds = 49.0 * 0.5 * kbar * (kbar + 1) * d.N;
+  const double sparse_s = visits * 0.5e-9 + adds * 0.7e-12 + 10e-6;
+  return dense_s < sparse_s;
 }
 
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return SFM_OK;
+  double* ws = static_cast<double*>(p->schur_ws);
+  SchurPlan pl;
   if (ba_schur_uses_mfma(p)) {
-    SchurPlan pl = make_plan(d);
+    pl = make_plan(d);
     pl.dbg = p->debug;
     const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
-    const int ntiles = pl.n_off + pl.nblk;
-    double* ws = static_cast<double*>(p->schur_ws);
     ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, ws, pl);
-    const int tile_blocks = (ntiles * RB * RB + 255) / 256;
-    const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
-    ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
   } else {
-    const size_t lds = sizeof(double) * 21 * (size_t)std::max(1, p->max_track);
-    if (lds > 64 * 1024) {
-      set_error("track of %d observations exceeds the pair kernel's LDS staging", p->max_track);
-      return SFM_E_SHAPE;
-    }
-    const int grid = std::min(d.N, 16 * ctx().num_cus);
-    ba_schur_pairs_kernel<<<grid, 64, lds, s>>>(d);
+    pl = make_pairs_plan(d);
+    const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, kPairLdsBytes, s>>>(d, p->schur_blk_ptr, ws, pl);
   }
+  const int ntiles = pl.n_off + pl.nblk;
+  const int tile_blocks = (ntiles * RB * RB + 255) / 256;
+  const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
+  ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
