@@ -44,7 +44,7 @@ extern "C" {
 
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
 #define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, pair kernel otherwise */
-#define SFM_SCHUR_PAIRS   1  /* per-point camera-pair kernel (f64 atomics) */
+#define SFM_SCHUR_PAIRS   1  /* sparse product: only camera pairs that share a point, accumulated in LDS tiles */
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
 
 #define SFM_OPT_SCHUR        1

@@ -275,7 +275,8 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
                                                 int p_beg, int p_end, double* __restrict__ slab, double* __restrict__ tile) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int t = tid; t < 7 * CB * TP; t += PAIR_THREADS) tile[t] = 0.0;
+  const int nr = 7 * min(CB, d.V - ti * CB), nc = 7 * min(CB, d.V - tj * CB);      // used part of the tile
+  for (int t = tid; t < nr * TP; t += PAIR_THREADS) tile[t] = 0.0;
   __syncthreads();
   const double* __restrict__ Z = d.Z;
   const int* __restrict__ cam_idx = d.cam_idx;
@@ -347,8 +348,8 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
     bp2 = bp3;
   }
   __syncthreads();
-  for (int t = tid; t < 7 * CB * 7 * CB; t += PAIR_THREADS) {
-    const int r = t / (7 * CB), c = t - r * (7 * CB);
+  for (int t = tid; t < nr * nc; t += PAIR_THREADS) {        // ba_schur_reduce never reads beyond the last camera
+    const int r = t / nc, c = t - r * nc;
     slab[r * RB + c] = tile[r * TP + c];
   }
 }
@@ -469,7 +470,8 @@ static SchurPlan make_plan(const BaDev& d) {
 }
 
 // Work split of the sparse product: every tile gets the same number of point chunks, about two workgroups per
-// CU in total (one is resident per CU: 128 KB of LDS, 16 waves), at least 64 points per chunk.
+// CU in total (one is resident per CU: 128 KB of LDS, 16 waves), at least one point per wave
+// (small scenes are latency-bound: a visit costs ~3 us per wave, so spread them over as many waves as possible).
 static SchurPlan make_pairs_plan(const BaDev& d) {
   SchurPlan pl;
   pl.dbg = 0;
@@ -477,7 +479,7 @@ static SchurPlan make_pairs_plan(const BaDev& d) {
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
   const int ntiles = pl.n_off + pl.nblk;
   int chunks = std::max(1, 2 * ctx().num_cus / ntiles);
-  chunks = std::max(1, std::min(chunks, (d.N + 63) / 64));
+  chunks = std::max(1, std::min(chunks, (d.N + PAIR_WAVES - 1) / PAIR_WAVES));
   const int ppc = (d.N + chunks - 1) / chunks;
   chunks = (d.N + ppc - 1) / std::max(1, ppc);
   pl.chunks_off = pl.n_off ? chunks : 0;
