@@ -44,6 +44,7 @@ def algorithmic_costs(n_cams, pt_ptr, n_obs):
         "solve": dict(bound="mfma", flops=p ** 3 / 3.0 + 2.0 * p * p, bytes=8.0 * p * p),
         "backsub": dict(bound="hbm", bytes=20.0 * n_obs + 52.0 * n_pts, flops=300.0 * n_obs + 60.0 * n_pts),
         "prep": dict(bound="hbm", bytes=56.0 * n_cams + 152.0 * n_cams, flops=100.0 * n_cams),
+        "reduce": dict(bound="hbm", bytes=8.0 * (p * p / 2.0 + p), flops=0.0),     # [S | rhs] written once
     }
 
 
@@ -155,6 +156,8 @@ def main():
         achieved = c["bytes"] / (dom_avg_ms * 1e-3) / 1e9
         roofline = dict(kernel="ba_" + dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=achieved / HBM_PEAK_GBS)
+    if dominant == "schur":      # the product kernel alone is bracketed (ba_schur_reduce is its own class)
+        roofline["kernel"] = "ba_schur_pairs" if args.schur == "pairs" or args.config != "C3" else "ba_schur_mfma"
     roofline["avg_launch_ms"] = dom_avg_ms
     roofline["launches"] = dom_n
     roofline["traffic"] = None
@@ -162,7 +165,8 @@ def main():
     if os.path.exists(tfile):
         try:      # a kernel class may be several kernels (schur = schur_mfma + schur_reduce, solve = chol_step x11 + back_solve)
             tj = json.load(open(tfile))
-            prefix = {"solve": ("ba_chol_step", "ba_back_solve")}.get(dominant, ("ba_" + dominant,))
+            prefix = {"solve": ("ba_chol_step", "ba_back_solve"), "schur": ("ba_schur_mfma", "ba_schur_pairs"),
+                      "reduce": ("ba_schur_reduce",)}.get(dominant, ("ba_" + dominant,))
             per = {k: v for k, v in tj.items() if k.startswith(prefix) and isinstance(v, (int, float))}
             if per:
                 mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32}
@@ -188,6 +192,25 @@ def main():
         "kernel_ms": breakdown,
         "roofline": roofline,
     }
+    # whole-iteration HBM figures per rank (north_star: achieved HBM-bandwidth fraction at every N): algorithmic
+    # bytes of one iteration (20 M + 52 N + 112 V) and, when profiles/traffic.json matches
+    # this configuration's kernels, the bytes rocprofv3's PMC passes measured per iteration (materialised
+    # intermediates such as the dense Z included), both over the measured time of one iteration
+    iter_s = elapsed / args.steps
+    alg_bytes = 20 * int(cam_l.shape[0]) + 52 * (int(ptr_l.shape[0]) - 1) + 112 * scene.n_cams
+    out["hbm"] = {"algorithmic_bytes_per_iteration": alg_bytes, "algorithmic_GBps": alg_bytes / iter_s / 1e9,
+                  "algorithmic_frac_of_peak": alg_bytes / iter_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
+                  "measured_bytes_per_iteration": None}
+    if os.path.exists(tfile) and args.config == "C3" and args.schur == "auto":
+        try:
+            tj = json.load(open(tfile))
+            mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32, "ba_cam_prep": 0}
+            meas = sum(v * mult.get(k, 1) for k, v in tj.items() if k.startswith("ba_") and isinstance(v, (int, float)))
+            out["hbm"].update({"measured_bytes_per_iteration": meas, "measured_GBps": meas / iter_s / 1e9,
+                               "measured_frac_of_peak": meas / iter_s / 1e9 / HBM_PEAK_GBS,
+                               "measured_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, 1-GPU C3 run)"})
+        except Exception:
+            pass
 
     # ---- CPU baseline (rank 0, N = 1): the NumPy block-sparse oracle, 3 iterations of the same scene
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -57,7 +57,8 @@ extern "C" {
 #define SFM_K_SCHUR      2
 #define SFM_K_SOLVE      3
 #define SFM_K_BACKSUB    4
-#define SFM_K_COUNT      5
+#define SFM_K_REDUCE     5  /* ba_schur_reduce: split-K slabs + camera accumulators -> [S | rhs] */
+#define SFM_K_COUNT      6
 
 /* ---- library / device ------------------------------------------------------------------------ */
 int sfm_version(void);

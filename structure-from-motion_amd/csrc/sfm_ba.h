@@ -102,6 +102,7 @@ namespace sfm {
 int ba_schur_plan(sfm_ba_problem* p);
 int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
+void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);

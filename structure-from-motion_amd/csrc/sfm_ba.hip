@@ -724,7 +724,7 @@ static void launch_backsub(const sfm_ba_problem* p, int g, int grid, size_t lds,
   }
 }
 
-static void tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
+void ba_tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
   if (!(p->timing & (1 << kid))) return;
   KernelTimer& t = p->timers[kid];
   if (begin) {
@@ -743,9 +743,9 @@ static void tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
 int ba_enqueue_prep(sfm_ba_problem* p) {
   hipStream_t s = ctx().stream;
   const BaDev& d = p->dev;
-  tick(p, SFM_K_PREP, true, s);
+  ba_tick(p, SFM_K_PREP, true, s);
   ba_cam_prep_kernel<<<(d.V + 63) / 64, 64, 0, s>>>(d.V, d.cams, d.prep[p->cur], d.status);
-  tick(p, SFM_K_PREP, false, s);
+  ba_tick(p, SFM_K_PREP, false, s);
   SFM_HIP(hipGetLastError());
   p->prep_valid = true;
   return SFM_OK;
@@ -762,7 +762,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   int grid = std::min((d.N + gpb - 1) / gpb, kLinGridPerCu * ctx().num_cus);
   if (grid < 1) grid = 1;
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);
-  tick(p, SFM_K_LINEARIZE, true, s);
+  ba_tick(p, SFM_K_LINEARIZE, true, s);
   p->quirks = quirks;
   const bool dense_z = ba_schur_uses_mfma(p);
   if (dense_z) SFM_TRY(ba_schur_prepare_dense(p, s));
@@ -782,18 +782,16 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
     else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
   }
   p->lin_rows = mode >= 1 ? grid : 0;
-  tick(p, SFM_K_LINEARIZE, false, s);
+  ba_tick(p, SFM_K_LINEARIZE, false, s);
   SFM_HIP(hipGetLastError());
-  tick(p, SFM_K_SCHUR, true, s);
   SFM_TRY(ba_enqueue_schur(p, s));
-  tick(p, SFM_K_SCHUR, false, s);
   return SFM_OK;
 }
 
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = ctx().stream;
   const BaDev& d = p->dev;
-  tick(p, SFM_K_SOLVE, true, s);
+  ba_tick(p, SFM_K_SOLVE, true, s);
   const int nbk = (d.P + NB - 1) / NB;
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
@@ -812,17 +810,17 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
       ba_back_solve_kernel<false, true><<<1, 256, 0, s>>>(d, p->cur);
     }
   }
-  tick(p, SFM_K_SOLVE, false, s);
+  ba_tick(p, SFM_K_SOLVE, false, s);
   SFM_HIP(hipGetLastError());
   const int g = pick_group(p);
   const int gpb = 256 / g;
   int grid = std::min((d.N + gpb - 1) / gpb, 4 * ctx().num_cus);
   if (grid < 1) grid = 1;
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 7);
-  tick(p, SFM_K_BACKSUB, true, s);
+  ba_tick(p, SFM_K_BACKSUB, true, s);
   if (lds <= 64 * 1024) launch_backsub<true>(p, g, grid, lds, s, lambda, quirks);
   else launch_backsub<false>(p, g, grid, 0, s, lambda, quirks);
-  tick(p, SFM_K_BACKSUB, false, s);
+  ba_tick(p, SFM_K_BACKSUB, false, s);
   SFM_HIP(hipGetLastError());
   p->red_clean = true;      // ba_backsub_kernel cleared [S | rhs]
   p->cur ^= 1;      // ba_back_solve_kernel prepared the updated cameras into the other slot

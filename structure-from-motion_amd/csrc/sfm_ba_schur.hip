@@ -567,16 +567,22 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     pl = make_plan(d);
     pl.dbg = p->debug;
     const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    ba_tick(p, SFM_K_SCHUR, true, s);
     ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, ws, pl);
+    ba_tick(p, SFM_K_SCHUR, false, s);
   } else {
     pl = make_pairs_plan(d);
     const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    ba_tick(p, SFM_K_SCHUR, true, s);
     ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, kPairLdsBytes, s>>>(d, p->schur_blk_ptr, ws, pl);
+    ba_tick(p, SFM_K_SCHUR, false, s);
   }
   const int ntiles = pl.n_off + pl.nblk;
   const int tile_blocks = (ntiles * RB * RB + 255) / 256;
   const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
+  ba_tick(p, SFM_K_REDUCE, true, s);
   ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
+  ba_tick(p, SFM_K_REDUCE, false, s);
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }

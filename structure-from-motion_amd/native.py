@@ -17,8 +17,8 @@ E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE,
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
 SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA = 0, 1, 2
 OPT_SCHUR, OPT_TIMING, OPT_DEBUG = 1, 2, 3
-K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub")
+K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
 
 # every symbol include/sfm_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
