@@ -338,30 +338,47 @@ __global__ __launch_bounds__(256) void tri_linear_kernel(int m, int n_views, con
 // Quirk Q1 (default): the reference stores each point's 2 rows at [pt : pt+2], so only the u-row of
 // every point and the v-row of the LAST point survive (campose_processor.py:404-405).
 // ---------------------------------------------------------------------------------------------
-__device__ void solve7(double* A /*7x7 row-major, destroyed*/, double* b /*in: rhs, out: solution*/) {
-  // Gaussian elimination with partial pivoting (the reference uses np.linalg.inv = LU, campose:409)
-  for (int k = 0; k < 7; ++k) {
-    int piv = k;
-    double best = fabs(A[7 * k + k]);
-    for (int r = k + 1; r < 7; ++r)
-      if (fabs(A[7 * r + k]) > best) { best = fabs(A[7 * r + k]); piv = r; }
-    if (piv != k) {
-      for (int c = 0; c < 7; ++c) { double t = A[7 * k + c]; A[7 * k + c] = A[7 * piv + c]; A[7 * piv + c] = t; }
-      double t = b[k]; b[k] = b[piv]; b[piv] = t;
-    }
-    const double inv = 1.0 / A[7 * k + k];
-    for (int r = k + 1; r < 7; ++r) {
-      const double f = A[7 * r + k] * inv;
-      for (int c = k + 1; c < 7; ++c) A[7 * r + c] -= f * A[7 * k + c];
-      b[r] -= f * b[k];
+// (J^T J + lambda I) x = b for the 7x7 SPD normal equations, lower triangle packed row-wise (a[i(i+1)/2 + j]).
+// Fully unrolled Cholesky in registers (no pivoting needed for an SPD matrix; the reference inverts with LU,
+// campose:409 -- same solution to rounding).  a is destroyed, b becomes the solution.
+__device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
+  double inv[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    double d = a[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= a[j * (j + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+    inv[j] = 1.0 / sqrt(d);
+    a[j * (j + 1) / 2 + j] = d * inv[j];
+#pragma unroll
+    for (int i = j + 1; i < 7; ++i) {
+      double v = a[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= a[i * (i + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+      a[i * (i + 1) / 2 + j] = v * inv[j];
     }
   }
-  for (int k = 6; k >= 0; --k) {
-    double s = b[k];
-    for (int c = k + 1; c < 7; ++c) s -= A[7 * k + c] * b[c];
-    b[k] = s / A[7 * k + k];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {          // L y = b
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= a[i * (i + 1) / 2 + k] * b[k];
+    b[i] = v * inv[i];
+  }
+#pragma unroll
+  for (int i = 6; i >= 0; --i) {         // L^T x = y
+    double v = b[i];
+#pragma unroll
+    for (int k = i + 1; k < 7; ++k) v -= a[k * (k + 1) / 2 + i] * b[k];
+    b[i] = v * inv[i];
   }
 }
+
+// One workgroup per view.  The view's points (and their normalised keys, a constant of the problem) stay in
+// registers across all iterations when the view has at most 256 * PNP_CACHE points; per iteration every thread
+// linearises its points (35 accumulators), a DPP wave reduction + a 35-thread sum over the 4 waves gives the
+// normal equations, one lane solves them and prepares the next camera.
+constexpr int PNP_CACHE = 4;
 
 __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
                                                             const double* __restrict__ uv_pix,
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
   __shared__ double params[7];
   __shared__ double kinv[9];
   __shared__ double red[4][35];
+  __shared__ double sums[35];
   __shared__ int st_sh;
   const int view = blockIdx.x;
   const int base = offsets[view];
@@ -398,20 +416,34 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
   }
   __syncthreads();
 
+  // point p of this thread: homogeneous X and the normalised key (campose:390-395: inv(K) [u,v,h] / its z)
+  auto load_point = [&](int p, double (&pt)[6]) {
+    const size_t col = (size_t)base + p;
+    pt[0] = X[col]; pt[1] = X[(size_t)total + col]; pt[2] = X[2 * (size_t)total + col]; pt[3] = X[3 * (size_t)total + col];
+    const double u = uv_pix[col], v = uv_pix[(size_t)total + col], h = uv_pix[2 * (size_t)total + col];
+    const double m2 = kinv[6] * u + kinv[7] * v + kinv[8] * h;
+    pt[4] = (kinv[0] * u + kinv[1] * v + kinv[2] * h) / m2;
+    pt[5] = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2;
+  };
+  const bool cached = n <= 256 * PNP_CACHE;
+  double pts[PNP_CACHE][6];
+  if (cached) {
+#pragma unroll
+    for (int c = 0; c < PNP_CACHE; ++c)
+      if (tid + 256 * c < n) load_point(tid + 256 * c, pts[c]);
+  }
+
   for (int it = 0; it < iters && st_sh == SFM_OK; ++it) {
     double acc[35];
 #pragma unroll
     for (int k = 0; k < 35; ++k) acc[k] = 0;
-    for (int p = tid; p < n; p += blockDim.x) {
-      const size_t col = (size_t)base + p;
-      const double x = X[col], y = X[(size_t)total + col], z = X[2 * (size_t)total + col], w = X[3 * (size_t)total + col];
-      const double u = uv_pix[col], v = uv_pix[(size_t)total + col], h = uv_pix[2 * (size_t)total + col];
+    CamPrep c = cam;                                   // LDS -> registers once per iteration
+    auto accumulate = [&](const double (&pt)[6], int p) {
       double pc[3], jp[14];
-      project_cam(cam, x, y, z, w, pc);
-      jac_cam(cam, x, y, z, pc, quirks, jp);
-      const double m2 = kinv[6] * u + kinv[7] * v + kinv[8] * h;
-      const double eu = (kinv[0] * u + kinv[1] * v + kinv[2] * h) / m2 - pc[0] / pc[2];
-      const double ev = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2 - pc[1] / pc[2];
+      project_cam(c, pt[0], pt[1], pt[2], pt[3], pc);
+      const double iz = 1.0 / pc[2];
+      jac_cam_iz(c, pt[0], pt[1], pt[2], pc, iz, quirks, jp);
+      const double eu = pt[4] - pc[0] * iz, ev = pt[5] - pc[1] * iz;
       const bool use_v = !(quirks & SFM_Q1_PNP_ROW_OVERLAP) || (p == n - 1);
       int k = 0;
 #pragma unroll
@@ -431,6 +463,17 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
 #pragma unroll
         for (int i = 0; i < 7; ++i) acc[28 + i] += jp[7 + i] * ev;
       }
+    };
+    if (cached) {
+#pragma unroll
+      for (int cc = 0; cc < PNP_CACHE; ++cc)
+        if (tid + 256 * cc < n) accumulate(pts[cc], tid + 256 * cc);
+    } else {
+      for (int p = tid; p < n; p += blockDim.x) {
+        double pt[6];
+        load_point(p, pt);
+        accumulate(pt, p);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 35; ++k) {
@@ -438,21 +481,18 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
       if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
+    if (tid < 35) sums[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
     if (tid == 0) {
-      double A[49], b[7];
-      int k = 0;
-      for (int i = 0; i < 7; ++i)
-        for (int j = 0; j <= i; ++j) {
-          const double s = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-          A[7 * i + j] = s;
-          A[7 * j + i] = s;
-          ++k;
-        }
+      double a[28], b[7];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) a[k] = sums[k];
+#pragma unroll
       for (int i = 0; i < 7; ++i) {
-        A[7 * i + i] += lambda;
-        b[i] = red[0][28 + i] + red[1][28 + i] + red[2][28 + i] + red[3][28 + i];
+        a[i * (i + 1) / 2 + i] += lambda;
+        b[i] = sums[28 + i];
       }
-      solve7(A, b);
+      solve7_spd(a, b);
       for (int i = 0; i < 7; ++i) params[i] += b[i];
       const double nq = sqrt(params[3] * params[3] + params[4] * params[4] + params[5] * params[5] + params[6] * params[6]);
       for (int i = 3; i < 7; ++i) params[i] /= nq;
@@ -487,6 +527,8 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
 //                          threshold (campose:544-554) -> inlier count
 //   pnp_inlier_mask_kernel inlier mask of the winning hypothesis
 // ---------------------------------------------------------------------------------------------
+// One wave per hypothesis: lanes 0..11 build the rows of the 12x12 design matrix (campose:588-611), lanes
+// 16..27 the identity; jacobi_rows_wave leaves B V in the first group and V in the second.
 __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, const int* __restrict__ samples /*[n_hyp][6]*/,
                                                            const double* __restrict__ uv_pix /*[3][n]*/,
                                                            const double* __restrict__ X /*[4][n]*/,
@@ -494,7 +536,8 @@ __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, con
                                                            double* __restrict__ R_out /*[n_hyp][9]*/,
                                                            double* __restrict__ C_out /*[n_hyp][3]*/,
                                                            double* __restrict__ proj_out /*[n_hyp][12]*/) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.x;
+  const int lane = threadIdx.x;
   if (h >= n_hyp) return;
   const double* K = Kmat;
   const double idet = 1.0 / det3(K);
@@ -502,31 +545,49 @@ __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, con
   ki[0] = (K[4] * K[8] - K[5] * K[7]) * idet; ki[1] = (K[2] * K[7] - K[1] * K[8]) * idet; ki[2] = (K[1] * K[5] - K[2] * K[4]) * idet;
   ki[3] = (K[5] * K[6] - K[3] * K[8]) * idet; ki[4] = (K[0] * K[8] - K[2] * K[6]) * idet; ki[5] = (K[2] * K[3] - K[0] * K[5]) * idet;
   ki[6] = (K[3] * K[7] - K[4] * K[6]) * idet; ki[7] = (K[1] * K[6] - K[0] * K[7]) * idet; ki[8] = (K[0] * K[4] - K[1] * K[3]) * idet;
-  double W[12][12], V[12][12];
-  for (int s6 = 0; s6 < 6; ++s6) {
-    const int idx = samples[6 * h + s6];
+  double row[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) row[c] = 0.0;
+  if (lane < 12) {
+    const int idx = samples[6 * h + lane / 2];
     const double u = uv_pix[idx], v = uv_pix[(size_t)n + idx], w = uv_pix[2 * (size_t)n + idx];
     const double p0 = ki[0] * u + ki[1] * v + ki[2] * w;       // key in camera coordinates (campose:535, not re-normalised)
     const double p1 = ki[3] * u + ki[4] * v + ki[5] * w;
     const double p2 = ki[6] * u + ki[7] * v + ki[8] * w;
     const double x = X[idx], y = X[(size_t)n + idx], z = X[2 * (size_t)n + idx];
-    double* r0 = W[2 * s6];
-    double* r1 = W[2 * s6 + 1];
-    r0[0] = p2 * x; r0[1] = p2 * y; r0[2] = p2 * z; r0[3] = p2; r0[4] = 0; r0[5] = 0; r0[6] = 0; r0[7] = 0;
-    r0[8] = -p0 * x; r0[9] = -p0 * y; r0[10] = -p0 * z; r0[11] = -p0;
-    r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = 0; r1[4] = p2 * x; r1[5] = p2 * y; r1[6] = p2 * z; r1[7] = p2;
-    r1[8] = -p1 * x; r1[9] = -p1 * y; r1[10] = -p1 * z; r1[11] = -p1;
+    const double pm = (lane & 1) ? p1 : p0;
+    const int o = (lane & 1) ? 4 : 0;                          // even rows fill columns 0..3, odd rows 4..7
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double xc = c == 0 ? x : (c == 1 ? y : (c == 2 ? z : 1.0));
+      row[c] = o == 0 ? p2 * xc : 0.0;
+      row[4 + c] = o == 4 ? p2 * xc : 0.0;
+      row[8 + c] = -pm * xc;
+    }
+  } else if (lane >= 16 && lane < 28) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) row[c] = (c == lane - 16) ? 1.0 : 0.0;
   }
-  jacobi_right_vectors<12>(W, V, 30);
+  jacobi_rows_wave<12>(row, lane, 30);
+  // column of smallest norm of B V -> the null vector is that column of V (rows in lanes 16..27)
   int best = 0;
   double bn = 0;
+#pragma unroll
   for (int c = 0; c < 12; ++c) {
-    double nn = 0;
-    for (int k = 0; k < 12; ++k) nn += W[k][c] * W[k][c];
+    const double nn = wave_lane0(group_sum<16>(lane < 16 ? row[c] * row[c] : 0.0));
     if (c == 0 || nn < bn) { bn = nn; best = c; }
   }
+  double mine = 0.0;
+#pragma unroll
+  for (int c = 0; c < 12; ++c) mine = (c == best) ? row[c] : mine;
   double cam[12];
-  for (int k = 0; k < 12; ++k) cam[k] = V[k][best];          // cam_mat (3x4) row-major (campose:618)
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {                                // cam_mat (3x4) row-major (campose:618), on every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(mine), 16 + k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), 16 + k);
+    cam[k] = __hiloint2double(hi, lo);
+  }
+  if (lane != 0) return;
   // polar factor of the 3x3 left block and its largest singular value (campose:622-626)
   double B3[3][3], V3[3][3];
   for (int i = 0; i < 3; ++i)
@@ -814,7 +875,7 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const do
   SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(12 * (size_t)n_hyp));
   SFM_TRY(dCnt.alloc(n_hyp)); SFM_TRY(dMask.alloc(n));
-  pnp_six_point_kernel<<<(n_hyp + 63) / 64, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
+  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
   pnp_score_kernel<<<n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
   SFM_HIP(hipGetLastError());
   std::vector<int> counts(n_hyp);

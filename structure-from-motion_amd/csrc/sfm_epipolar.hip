@@ -3,8 +3,8 @@
 //
 //   fund_normalize_kernel    one workgroup: centroid + mean-distance normalisation of both point sets
 //                            (epipolar_processor.py:97-137) -> pairs [n][4] and the two 3x3 transforms
-//   fund_eight_point_kernel  thread per hypothesis: 8x9 design matrix -> null vector by one-sided Jacobi
-//                            (9x9 with a zero row), rank-2 projection by a 3x3 Jacobi SVD, / f[2][2]
+//   fund_eight_point_kernel  wave per hypothesis: 8x9 design matrix -> null vector by a wave-cooperative one-sided
+//                            Jacobi (9x9 with a zero row), rank-2 projection by a 3x3 Jacobi SVD, / f[2][2]
 //                            (epipolar:140-193)
 //   fund_score_kernel        workgroup per hypothesis: |x_r^T F x_l| < threshold over all pairs (epipolar:231-239)
 //   fund_finish_kernel       inlier mask of the winner + de-normalisation (epipolar:251-267)
@@ -66,29 +66,51 @@ __global__ __launch_bounds__(256) void fund_normalize_kernel(int n, const double
   }
 }
 
-// epipolar_processor.py:140-193 for the eight pairs idx[0..7]; returns SFM_OK or SFM_E_RANK.
-__device__ int eight_point(const double* __restrict__ pairs, const int* idx, double* F) {
-  double W[9][9], V[9][9];
-  for (int r = 0; r < 8; ++r) {
-    const double* p = pairs + 4 * (size_t)idx[r];
+// epipolar_processor.py:140-193, one wave per hypothesis: lanes 0..7 hold the rows of the 8x9 design matrix
+// (lane 8 a zero row), lanes 16..24 the identity; after jacobi_rows_wave the null vector is the column of V
+// whose B V column has the smallest norm.  The 3x3 rank-2 projection runs on lane 0.
+__global__ __launch_bounds__(64) void fund_eight_point_kernel(int n_hyp, const int* __restrict__ samples, const double* __restrict__ pairs,
+                                                              double* __restrict__ F_out, int* __restrict__ status) {
+  const int h = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (h >= n_hyp) return;
+  double row[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) row[c] = 0.0;
+  if (lane < 8) {
+    const int idx = samples ? samples[8 * h + lane] : lane;
+    const double* p = pairs + 4 * (size_t)idx;
     const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
-    W[r][0] = x1 * x2; W[r][1] = y1 * x2; W[r][2] = x2;
-    W[r][3] = x1 * y2; W[r][4] = y1 * y2; W[r][5] = y2;
-    W[r][6] = x1;      W[r][7] = y1;      W[r][8] = 1.0;
+    row[0] = x1 * x2; row[1] = y1 * x2; row[2] = x2;
+    row[3] = x1 * y2; row[4] = y1 * y2; row[5] = y2;
+    row[6] = x1;      row[7] = y1;      row[8] = 1.0;
+  } else if (lane >= 16 && lane < 25) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) row[c] = (c == lane - 16) ? 1.0 : 0.0;
   }
-  for (int c = 0; c < 9; ++c) W[8][c] = 0.0;
-  jacobi_right_vectors<9>(W, V, 40);
+  jacobi_rows_wave<9>(row, lane, 40);
   int best = 0;
   double bn = 0;
+#pragma unroll
   for (int c = 0; c < 9; ++c) {
-    double nn = 0;
-    for (int k = 0; k < 9; ++k) nn += W[k][c] * W[k][c];
+    const double nn = wave_lane0(group_sum<16>(lane < 16 ? row[c] * row[c] : 0.0));
     if (c == 0 || nn < bn) { bn = nn; best = c; }
   }
+  double mine = 0.0;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) mine = (c == best) ? row[c] : mine;
+  double f[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {                                  // f_ = reshape(null vector, (3, 3))
+    const int lo = __builtin_amdgcn_readlane(__double2loint(mine), 16 + k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(mine), 16 + k);
+    f[k] = __hiloint2double(hi, lo);
+  }
+  if (lane != 0) return;
   double B[3][3], V3[3][3], sig[3];
   int ord[3];
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) B[i][j] = V[3 * i + j][best];       // f_ = reshape(null vector, (3, 3))
+    for (int j = 0; j < 3; ++j) B[i][j] = f[3 * i + j];
   svd3(B, V3, sig, ord);
   // matrix_rank tolerance: sigma_max * max(M, N) * eps (numpy.linalg.matrix_rank)
   const double tol = sig[ord[0]] * 3.0 * 2.220446049250313e-16;
@@ -98,19 +120,8 @@ __device__ int eight_point(const double* __restrict__ pairs, const int* idx, dou
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)       // u diag(s0, s1, 0) v^T = sum over the two largest of (sigma u)_i v_j
       f2[3 * i + j] = B[i][ord[0]] * V3[j][ord[0]] + B[i][ord[1]] * V3[j][ord[1]];
-  for (int k = 0; k < 9; ++k) F[k] = f2[k] / f2[8];
-  return st;
-}
-
-__global__ __launch_bounds__(64) void fund_eight_point_kernel(int n_hyp, const int* __restrict__ samples, const double* __restrict__ pairs,
-                                                              double* __restrict__ F_out, int* __restrict__ status) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= n_hyp) return;
-  int idx[8];
-  for (int k = 0; k < 8; ++k) idx[k] = samples ? samples[8 * h + k] : k;
-  double F[9];
-  status[h] = eight_point(pairs, idx, F);
-  for (int k = 0; k < 9; ++k) F_out[9 * (size_t)h + k] = F[k];
+  for (int k = 0; k < 9; ++k) F_out[9 * (size_t)h + k] = f2[k] / f2[8];
+  status[h] = st;
 }
 
 __device__ __forceinline__ bool fund_is_inlier(const double* F, const double* p, double threshold) {
@@ -242,7 +253,7 @@ int sfm_fundamental_eight_point(int n, const double* pairs, int n_hyp, const int
   DevBuf<int> dS, dSt;
   SFM_TRY(dP.upload(pairs, 4 * (size_t)n, s)); SFM_TRY(dS.upload(samples, 8 * (size_t)n_hyp, s));
   SFM_TRY(dF.alloc(9 * (size_t)n_hyp)); SFM_TRY(dSt.alloc(n_hyp));
-  fund_eight_point_kernel<<<(n_hyp + 63) / 64, 64, 0, s>>>(n_hyp, dS.p, dP.p, dF.p, dSt.p);
+  fund_eight_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, dS.p, dP.p, dF.p, dSt.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dF.download(F_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dSt.download(status, n_hyp, s));
   SFM_HIP(hipStreamSynchronize(s));
@@ -267,7 +278,7 @@ int sfm_fundamental_ransac(int n, const double* left, const double* right, int n
   SFM_TRY(dP.alloc(4 * (size_t)n)); SFM_TRY(dT.alloc(18)); SFM_TRY(dF.alloc(9 * (size_t)n_hyp)); SFM_TRY(dFp.alloc(9));
   SFM_TRY(dSt.alloc(n_hyp)); SFM_TRY(dCnt.alloc(n_hyp)); SFM_TRY(dMask.alloc(n));
   fund_normalize_kernel<<<1, 256, 0, s>>>(n, dL.p, dR.p, dP.p, dT.p);
-  fund_eight_point_kernel<<<(n_hyp + 63) / 64, 64, 0, s>>>(n_hyp, exact ? nullptr : dS.p, dP.p, dF.p, dSt.p);
+  fund_eight_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, exact ? nullptr : dS.p, dP.p, dF.p, dSt.p);
   if (!exact) fund_score_kernel<<<n_hyp, 256, 0, s>>>(n, dF.p, dP.p, threshold, dCnt.p);
   SFM_HIP(hipGetLastError());
   std::vector<int> st(n_hyp), counts(n_hyp, 8);
