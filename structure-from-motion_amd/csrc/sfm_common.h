@@ -190,7 +190,9 @@ __device__ __forceinline__ void jacobi_rows_wave(double (&row)[N], int lane, int
         const double al = wave_lane0(group_sum<16>(is_b ? bp * bp : 0.0));
         const double be = wave_lane0(group_sum<16>(is_b ? bq * bq : 0.0));
         const double ga = wave_lane0(group_sum<16>(is_b ? bp * bq : 0.0));
-        if (ga != 0.0 && ga * ga > 1e-34 * (al * be)) {                    // wave-uniform
+        // |cos(angle)| > 3e-16: a few ulp above what the Newton-refined rotations can reach (the 1e-17 of the
+        // scalar version would keep every pair "rotating" until max_sweeps)
+        if (ga != 0.0 && ga * ga > 1e-31 * (al * be)) {                    // wave-uniform
           rotated = true;
           const double ze = (be - al) * rcp_nr(2.0 * ga);
           const double az = fabs(ze);
