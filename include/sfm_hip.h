@@ -43,7 +43,7 @@ extern "C" {
 #define SFM_QUIRKS_REFERENCE    3
 
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
-#define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, pair kernel otherwise */
+#define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, sparse LDS-tile product otherwise (fitted cost models) */
 #define SFM_SCHUR_PAIRS   1  /* sparse product: only camera pairs that share a point, accumulated in LDS tiles */
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
 

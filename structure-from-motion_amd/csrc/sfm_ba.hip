@@ -61,7 +61,7 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // LDS_MODE 2: [V][19] prepared cameras + [V][35] camera-side accumulators in LDS (V <= 151);
 // LDS_MODE 1: accumulators only, cameras read from global/L2 (V <= 234); LDS_MODE 0: global atomics.
 // ---------------------------------------------------------------------------------------------
-// DENSE_Z: Z_o goes to its 7x3 slot of the dense Zd (MFMA product); otherwise to the SoA Z of the pair kernel.
+// DENSE_Z: Z_o goes to its 7x3 slot of the dense Zd (MFMA product); otherwise to the AoS Z of the sparse product.
 template <int G, int LDS_MODE, bool DENSE_Z>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   extern __shared__ double lds[];
@@ -690,7 +690,7 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ S, int ld, int P
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-constexpr int kLinGridPerCu = 3;   // ba_linearize workgroups per CU (168 VGPRs -> 3 waves/SIMD)
+constexpr int kLinGridPerCu = 3;   // ba_linearize workgroups per CU (132 VGPRs -> 3 waves/SIMD; forcing 4 measured 10 % slower)
 
 static int pick_group(const sfm_ba_problem* p) {
   // lanes per point: smallest power of two >= mean track length (clamped to [4, 64]); longer tracks loop
