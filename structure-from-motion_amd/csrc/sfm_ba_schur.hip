@@ -72,7 +72,9 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
                                              const int (&ob)[5], int wr, int wc, double4_ (&acc)[8]) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: LDS-DMA destinations stay in SGPRs
-  constexpr int NA = DIAG ? NS : 4, NB = DIAG ? NS : 2, NM = DIAG ? NS : 8;
+  // NS: diagonal tile = this wave's lower 16x16 sub-tiles (0..5); off-diagonal tile = its 16-row strips of the
+  // row block (0..4; fewer than 4 only in the last, partly filled block), each against its two column strips
+  constexpr int NA = NS > 0 ? NS : 1, NB = DIAG ? NA : 2, NM = DIAG ? NS : 2 * NS;
   constexpr int BATCH = (DIAG ? 1 : 2) * (KSL / N_WAVES);      // DMA instructions per wave and slab
   double a[2][NA], b[2][NB];
   const double* z0 = img + (lane >> 4) * ZLD + (lane & 15);
@@ -81,9 +83,9 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
     if (DIAG) {
 #pragma unroll
       for (int t = 0; t < NS; ++t) { a[set][t] = z[oa[t]]; b[set][t] = z[ob[t]]; }
-    } else {
+    } else if (NS > 0) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x) a[set][x] = z[wr + 16 * x];
+      for (int x = 0; x < NS; ++x) a[set][x] = z[wr + 16 * x];
 #pragma unroll
       for (int y = 0; y < 2; ++y) b[set][y] = z[STAGE + wc + 16 * y];
     }
@@ -121,6 +123,10 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
         dma_piece(dma_slab, i);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (dma_slab >= 0) {                     // a wave with fewer MFMAs than DMA pieces still stages its rows
+#pragma unroll
+      for (int j = NM; j < BATCH; ++j) dma_piece(dma_slab, j);
     }
     // The operand reads issued before these MFMAs completed long ago (the wave spent >= 4 x 64 cycles issuing
     // them): an explicit lgkmcnt(0) here is free and leaves no pending LDS read at the next load_ops, so the
@@ -167,7 +173,7 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
 template <bool DIAG>
 __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, size_t zp, double* __restrict__ slab, int ti,
                                                 int tj, int k_beg, int k_end, double* __restrict__ img /*[NSTG][2][STAGE]*/,
-                                                int dbg) {
+                                                int ra /*16-row strips of block ti that hold cameras*/, int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const double* pa = Zd + (size_t)RB * ti;
@@ -181,7 +187,7 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
   if (DIAG) {
     for (int s = 0; s < 5; ++s) {
       const int idx = wave + N_WAVES * s;
-      if (idx < 36) {
+      if (idx < ra * (ra + 1) / 2) {
         int x = 0;
         while ((x + 1) * (x + 2) / 2 <= idx) ++x;
         sx[s] = __builtin_amdgcn_readfirstlane(x);
@@ -196,23 +202,35 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
   for (int s = 0; s < 5; ++s) { oa[s] = 16 * sx[s]; ob[s] = 16 * sy[s]; }
   const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // off-diagonal tiles: this wave's 64x32 part
   const int nslab = (k_end - k_beg) / KSL;                   // chunk bounds are multiples of KSL
-  if (dbg & 5) {      // profiling ablations (1: no MFMA, 4: no staging DMA); results are wrong by design
+  // off-diagonal tiles: strips of the row block in this wave's 64-row half
+  const int nstrip = __builtin_amdgcn_readfirstlane(max(0, min(4, ra - 4 * (wave >> 2))));
+#define SCHUR_LOOP(D, N, M, L) schur_k_loop<D, N, M, L>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc)
+  if (dbg & 5) {      // profiling ablations (1: no MFMA, 4: no staging DMA) on full tiles; results are wrong by design
     const bool mm = !(dbg & 1), ld = !(dbg & 4);
     if (DIAG) {
-      if (mm) schur_k_loop<true, 5, true, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
-      else if (ld) schur_k_loop<true, 5, false, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
-      else schur_k_loop<true, 5, false, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      if (mm) SCHUR_LOOP(true, 5, true, false); else if (ld) SCHUR_LOOP(true, 5, false, true); else SCHUR_LOOP(true, 5, false, false);
     } else {
-      if (mm) schur_k_loop<false, 4, true, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
-      else if (ld) schur_k_loop<false, 4, false, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
-      else schur_k_loop<false, 4, false, false>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+      if (mm) SCHUR_LOOP(false, 4, true, false); else if (ld) SCHUR_LOOP(false, 4, false, true); else SCHUR_LOOP(false, 4, false, false);
     }
   } else if (DIAG) {
-    if (nsub == 5) schur_k_loop<true, 5, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
-    else schur_k_loop<true, 4, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+    switch (nsub) {
+      case 5: SCHUR_LOOP(true, 5, true, true); break;
+      case 4: SCHUR_LOOP(true, 4, true, true); break;
+      case 3: SCHUR_LOOP(true, 3, true, true); break;
+      case 2: SCHUR_LOOP(true, 2, true, true); break;
+      case 1: SCHUR_LOOP(true, 1, true, true); break;
+      default: SCHUR_LOOP(true, 0, true, true); break;
+    }
   } else {
-    schur_k_loop<false, 4, true, true>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc);
+    switch (nstrip) {
+      case 4: SCHUR_LOOP(false, 4, true, true); break;
+      case 3: SCHUR_LOOP(false, 3, true, true); break;
+      case 2: SCHUR_LOOP(false, 2, true, true); break;
+      case 1: SCHUR_LOOP(false, 1, true, true); break;
+      default: SCHUR_LOOP(false, 0, true, true); break;
+    }
   }
+#undef SCHUR_LOOP
   if (DIAG) {
 #pragma unroll
     for (int s = 0; s < 5; ++s)
@@ -223,25 +241,79 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
   } else {
 #pragma unroll
     for (int x = 0; x < 4; ++x)
+      if (x < nstrip) {                      // strips beyond the last camera are never read by ba_schur_reduce
 #pragma unroll
-      for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(wr + 16 * x + lk + 4 * r) * RB + wc + 16 * y + lr] = acc[2 * x + y][r];
+          for (int r = 0; r < 4; ++r) slab[(wr + 16 * x + lk + 4 * r) * RB + wc + 16 * y + lr] = acc[2 * x + y][r];
+      }
   }
 }
 
-// Work split of the MFMA product.  A diagonal tile issues 9 MFMAs per SIMD and k-step, an
-// off-diagonal one 16, so diagonal tiles get proportionally longer row chunks: every workgroup then
-// carries the same MFMA load.  Workgroup w:
-//   w <  n_off * chunks_off : off-diagonal tile w / chunks_off (pairs ti > tj in row-major order)
-//   else                    : diagonal tile (w - n_off * chunks_off) / chunks_diag
-// and its partial tile goes to slab w.
+// Work split of both products.  Tiles are the lower-triangular pairs of 18-camera blocks, in four classes with
+// their own chunking: off-diagonal tiles (ti > tj, row-major order) whose row block is full, off-diagonal tiles
+// of the LAST block (which may hold fewer than 18 cameras: its empty 16-row MFMA strips are skipped), full
+// diagonal tiles and the last diagonal tile.  A dense off-diagonal tile issues 2 x (strips of its row block)
+// MFMAs per SIMD and k-step (16 when full), a diagonal one the larger half of its lower sub-tiles (9 when full);
+// rows per chunk are inversely proportional, so every workgroup carries the same MFMA load.  Workgroup w's
+// partial tile goes to slab w; workgroups are numbered class by class, tile by tile, chunk by chunk.
 struct SchurPlan {
   int nblk, n_off;
-  int chunks_off, rpc_off;      // chunks per off-diagonal tile, Zd rows per chunk
-  int chunks_diag, rpc_diag;
+  int chunks[4], rpc[4];        // per class (0 off full, 1 off last row, 2 diag full, 3 diag last): chunks per tile,
+                                // rows of Zd (dense) or points (sparse) per chunk
+  int ra_last;                  // 16-row strips of the last block that hold cameras (1..8)
   int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
 };
+
+struct SchurTileRef { int ti, tj, cls, first, chunk; };
+
+__host__ __device__ inline int plan_tiles_in_class(const SchurPlan& pl, int cls) {
+  const int last_row = pl.nblk - 1;                       // off-diagonal tiles with ti == nblk - 1
+  return cls == 0 ? pl.n_off - last_row : (cls == 1 ? last_row : (cls == 2 ? pl.nblk - 1 : 1));
+}
+__host__ __device__ inline int plan_wgs(const SchurPlan& pl) {
+  int w = 0;
+  for (int c = 0; c < 4; ++c) w += plan_tiles_in_class(pl, c) * pl.chunks[c];
+  return w;
+}
+// tile index (off-diagonal tiles first in row-major (ti, tj) order, then the diagonal ones) -> blocks, class,
+// first workgroup
+__host__ __device__ inline SchurTileRef plan_tile(const SchurPlan& pl, int tile) {
+  SchurTileRef r;
+  r.chunk = 0;
+  const int n0 = plan_tiles_in_class(pl, 0), n1 = plan_tiles_in_class(pl, 1), n2 = plan_tiles_in_class(pl, 2);
+  if (tile < pl.n_off) {
+    int t = tile;
+    r.ti = 1;
+    while (t >= r.ti) { t -= r.ti; ++r.ti; }
+    r.tj = t;
+    if (tile < n0) { r.cls = 0; r.first = tile * pl.chunks[0]; }
+    else { r.cls = 1; r.first = n0 * pl.chunks[0] + (tile - n0) * pl.chunks[1]; }
+  } else {
+    r.ti = r.tj = tile - pl.n_off;
+    const int base = n0 * pl.chunks[0] + n1 * pl.chunks[1];
+    if (r.ti < n2) { r.cls = 2; r.first = base + r.ti * pl.chunks[2]; }
+    else { r.cls = 3; r.first = base + n2 * pl.chunks[2]; }
+  }
+  return r;
+}
+// workgroup -> tile and chunk
+__host__ __device__ inline SchurTileRef plan_locate(const SchurPlan& pl, int w) {
+  int tile0 = 0, w0 = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int nt = plan_tiles_in_class(pl, c), span = nt * pl.chunks[c];
+    if (w < w0 + span || c == 3) {
+      const int t = (w - w0) / pl.chunks[c];
+      // classes are stored off-full, off-last, diag-full, diag-last = exactly the tile index order
+      SchurTileRef r = plan_tile(pl, tile0 + t);
+      r.chunk = (w - w0) - t * pl.chunks[c];
+      return r;
+    }
+    w0 += span;
+    tile0 += nt;
+  }
+  return SchurTileRef{0, 0, 0, 0, 0};
+}
 
 // ---------------------------------------------------------------------------------------------
 // Sparse product (low visibility): the same 18-camera blocks and split-K slabs as the dense path, but a tile's
@@ -359,43 +431,24 @@ __global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, c
   extern __shared__ double lds_pairs[];
   double* tile = lds_pairs;
   const int w = blockIdx.x;
-  const int off_wgs = plan.n_off * plan.chunks_off;
   double* slab = ws + (size_t)w * (RB * RB);
-  if (w < off_wgs) {
-    int t = w / plan.chunks_off, ti = 1;
-    const int chunk = w - t * plan.chunks_off;
-    while (t >= ti) { t -= ti; ++ti; }
-    const int p_beg = chunk * plan.rpc_off;
-    pairs_tile_body<false>(d, blk_ptr, plan.nblk, ti, t, p_beg, min(d.N, p_beg + plan.rpc_off), slab, tile);
-  } else {
-    const int w2 = w - off_wgs;
-    const int ti = w2 / plan.chunks_diag;
-    const int chunk = w2 - ti * plan.chunks_diag;
-    const int p_beg = chunk * plan.rpc_diag;
-    pairs_tile_body<true>(d, blk_ptr, plan.nblk, ti, ti, p_beg, min(d.N, p_beg + plan.rpc_diag), slab, tile);
-  }
+  const SchurTileRef t = plan_locate(plan, w);
+  const int p_beg = t.chunk * plan.rpc[t.cls];
+  const int p_end = min(d.N, p_beg + plan.rpc[t.cls]);
+  if (t.ti != t.tj) pairs_tile_body<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
+  else pairs_tile_body<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
 }
 
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
   extern __shared__ double img[];               // [NSTG stages][A panel, B panel][KSL][ZLD]
   const int w = blockIdx.x;
-  const int off_wgs = plan.n_off * plan.chunks_off;
   double* slab = ws + (size_t)w * (RB * RB);
-  if (w < off_wgs) {
-    int t = w / plan.chunks_off, ti = 1;
-    const int chunk = w - t * plan.chunks_off;
-    while (t >= ti) { t -= ti; ++ti; }           // t-th pair (ti, tj) with ti > tj
-    const int k_beg = chunk * plan.rpc_off;
-    const int k_end = min(d.zrows, k_beg + plan.rpc_off);
-    schur_tile_body<false>(d.Zd, (size_t)d.zp, slab, ti, t, k_beg, k_end, img, plan.dbg);
-  } else {
-    const int w2 = w - off_wgs;
-    const int ti = w2 / plan.chunks_diag;
-    const int chunk = w2 - ti * plan.chunks_diag;
-    const int k_beg = chunk * plan.rpc_diag;
-    const int k_end = min(d.zrows, k_beg + plan.rpc_diag);
-    schur_tile_body<true>(d.Zd, (size_t)d.zp, slab, ti, ti, k_beg, k_end, img, plan.dbg);
-  }
+  const SchurTileRef t = plan_locate(plan, w);
+  const int k_beg = t.chunk * plan.rpc[t.cls];
+  const int k_end = min(d.zrows, k_beg + plan.rpc[t.cls]);
+  const int ra = (t.cls & 1) ? plan.ra_last : 8;          // strips of the row block that hold cameras
+  if (t.ti != t.tj) schur_tile_body<false>(d.Zd, (size_t)d.zp, slab, t.ti, t.tj, k_beg, k_end, img, ra, plan.dbg);
+  else schur_tile_body<true>(d.Zd, (size_t)d.zp, slab, t.ti, t.ti, k_beg, k_end, img, ra, plan.dbg);
 }
 
 // S(lower) -= sum over the tile's chunk slabs, un-padding block coordinates (block b, row r) -> camera
@@ -415,19 +468,8 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   if (idx >= ntiles * RB * RB) return;
   const int tile = idx / (RB * RB);
   const int e = idx - tile * (RB * RB);
-  int ti, tj, first, chunks;
-  if (tile < plan.n_off) {
-    int t = tile;
-    ti = 1;
-    while (t >= ti) { t -= ti; ++ti; }
-    tj = t;
-    first = tile * plan.chunks_off;
-    chunks = plan.chunks_off;
-  } else {
-    ti = tj = tile - plan.n_off;
-    first = plan.n_off * plan.chunks_off + ti * plan.chunks_diag;
-    chunks = plan.chunks_diag;
-  }
+  const SchurTileRef tr = plan_tile(plan, tile);
+  const int ti = tr.ti, tj = tr.tj, first = tr.first, chunks = plan.chunks[tr.cls];
   const int r = e / RB, c = e - r * RB;
   if (r >= 7 * CB || c >= 7 * CB) return;
   const int cam_r = ti * CB + r / 7, cam_c = tj * CB + c / 7;
@@ -442,30 +484,42 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   if (s != 0.0) atomicAdd(&d.red[(size_t)row * d.ld + col], -s);
 }
 
+// MFMAs per SIMD and k-step of a diagonal tile with `ra` strips: sub-tile idx goes to wave idx % 8, SIMD s hosts
+// waves s and s + 4.
+static int diag_cost(int ra) {
+  const int t = ra * (ra + 1) / 2;
+  int worst = 0;
+  for (int sd = 0; sd < 4; ++sd) {
+    int n = 0;
+    for (int w = sd; w < 8; w += 4) n += std::max(0, (t - w + 7) / 8);
+    worst = std::max(worst, n);
+  }
+  return std::max(1, worst);
+}
+
 static SchurPlan make_plan(const BaDev& d) {
   SchurPlan pl;
   pl.dbg = 0;
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
+  pl.ra_last = (7 * (d.V - (pl.nblk - 1) * CB) + 15) / 16;
   const int slabs = std::max(1, d.zrows / KSL);
   // ONE workgroup per CU in total (each needs 144 KB of LDS, so a CU hosts one at a time): a single even
-  // round pays the per-workgroup prologue / slab write once and halves the split-K slab traffic
-  // compared with two rounds.  chunks_diag : chunks_off = 9 : 16; shrink until everything fits one round.
-  auto fit = [&](double want, int& chunks, int& rpc) {
-    int c = std::max(1, std::min(slabs, (int)(want + 0.5)));
-    const int slabs_per = (slabs + c - 1) / c;
-    rpc = slabs_per * KSL;
-    chunks = (slabs + slabs_per - 1) / slabs_per;
-  };
-  double target = (double)ctx().num_cus;
-  for (int attempt = 0; attempt < 64; ++attempt) {
-    const double a = target / (pl.n_off + (9.0 / 16.0) * pl.nblk);
-    fit(a, pl.chunks_off, pl.rpc_off);
-    fit(a * 9.0 / 16.0, pl.chunks_diag, pl.rpc_diag);
-    if (pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag <= ctx().num_cus || target < 8) break;
-    target -= 1.0;
+  // round pays the per-workgroup prologue / slab write once.  Rows per chunk are inversely proportional to the
+  // class's MFMAs per k-step; shrink the common time budget until everything fits one round.
+  const double cost[4] = {16.0, 2.0 * pl.ra_last, 9.0, (double)diag_cost(pl.ra_last)};
+  double total = 0;
+  for (int c = 0; c < 4; ++c) total += cost[c] * plan_tiles_in_class(pl, c);
+  double budget = total * slabs / std::max(1, ctx().num_cus);      // cost x slabs per workgroup
+  for (int attempt = 0; attempt < 200; ++attempt) {
+    for (int c = 0; c < 4; ++c) {
+      int slabs_per = std::max(1, std::min(slabs, (int)(budget / cost[c])));
+      pl.chunks[c] = (slabs + slabs_per - 1) / slabs_per;
+      pl.rpc[c] = slabs_per * KSL;
+    }
+    if (plan_wgs(pl) <= ctx().num_cus) break;
+    budget *= 1.01;
   }
-  if (pl.n_off == 0) { pl.chunks_off = 0; pl.rpc_off = KSL; }
   return pl;
 }
 
@@ -477,14 +531,13 @@ static SchurPlan make_pairs_plan(const BaDev& d) {
   pl.dbg = 0;
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
+  pl.ra_last = 8;
   const int ntiles = pl.n_off + pl.nblk;
   int chunks = std::max(1, 2 * ctx().num_cus / ntiles);
   chunks = std::max(1, std::min(chunks, (d.N + PAIR_WAVES - 1) / PAIR_WAVES));
   const int ppc = (d.N + chunks - 1) / chunks;
   chunks = (d.N + ppc - 1) / std::max(1, ppc);
-  pl.chunks_off = pl.n_off ? chunks : 0;
-  pl.chunks_diag = chunks;
-  pl.rpc_off = pl.rpc_diag = std::max(1, ppc);
+  for (int c = 0; c < 4; ++c) { pl.chunks[c] = chunks; pl.rpc[c] = std::max(1, ppc); }
   return pl;
 }
 
@@ -497,8 +550,8 @@ int ba_schur_plan(sfm_ba_problem* p) {
   d.zrows = ((3 * d.N + KSL - 1) / KSL) * KSL;
   const SchurPlan pl = make_plan(d);
   const SchurPlan pp = make_pairs_plan(d);
-  const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
-  const int wgs_pairs = pp.n_off * pp.chunks_off + pp.nblk * pp.chunks_diag;
+  const int wgs = plan_wgs(pl);
+  const int wgs_pairs = plan_wgs(pp);
   const size_t ws_dense = sizeof(double) * (size_t)wgs * RB * RB;
   const size_t ws_pairs = sizeof(double) * (size_t)wgs_pairs * RB * RB;
   const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
@@ -566,13 +619,13 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   if (ba_schur_uses_mfma(p)) {
     pl = make_plan(d);
     pl.dbg = p->debug;
-    const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);
     ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
   } else {
     pl = make_pairs_plan(d);
-    const int wgs = pl.n_off * pl.chunks_off + pl.nblk * pl.chunks_diag;
+    const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);
     ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, kPairLdsBytes, s>>>(d, p->schur_blk_ptr, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
