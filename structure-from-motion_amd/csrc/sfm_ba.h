@@ -40,8 +40,7 @@ struct BaDev {
   double* lin_ws = nullptr; // [linearize workgroups][V][35] per-workgroup camera accumulators (U lower 28 | rhs 7)
   double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
   double* delta = nullptr;  // [ld] camera update
-  double* ldiag = nullptr;  // [ceil(P/32)][32][32] Cholesky factors of the diagonal blocks
-  double* ldiag_rd = nullptr;   // [ceil(P/32)][32] reciprocals of their diagonals
+  double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
   int* status = nullptr;    // [2] first failure code, camera index
   unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };

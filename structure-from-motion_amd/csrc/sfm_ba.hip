@@ -323,7 +323,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
 // X = T L_d^-T.  Column j of L_d is published through a 32-double LDS buffer and read back with
 // wave-uniform addresses (LDS broadcast): one ds_read + one FMA per trailing entry, no SGPR hazards.
 // Single wave => its LDS operations execute in order; no barrier is needed.
-__device__ __forceinline__ double chol_trsm_rows(double (&a)[NB], double (*colbuf)[64], int lane) {
+__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], double (*colbuf)[64], int lane) {
   // Software-pipelined over columns.  Per column j:
   //   1. pivot chain: inv = rsqrt(d_jj), scale column j                       (critical path)
   //   2. deferred bulk update with column j-1, whose entries were read back from LDS one step ago
@@ -332,14 +332,12 @@ __device__ __forceinline__ double chol_trsm_rows(double (&a)[NB], double (*colbu
   //      issue the LDS reads whose values step j+1 consumes in (2)
   // Every LDS row is written once and read once, so there are no WAR hazards for the scheduler to respect.
   constexpr int FAST = 2;
-  double my_inv = 1.0;      // 1 / l_jj for j == lane: the back substitution multiplies by it instead of dividing
   double lk[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) lk[k] = 0.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const double inv = rsqrt_nr(lane_bcast(a[j], j));
-    my_inv = (lane == j) ? inv : my_inv;
     if (j > 0) {
 #pragma unroll
       for (int k = j + FAST; k < NB; ++k) a[k] -= a[j - 1] * lk[k];      // column j-1, entries k >= (j-1)+1+FAST
@@ -351,7 +349,6 @@ __device__ __forceinline__ double chol_trsm_rows(double (&a)[NB], double (*colbu
 #pragma unroll
     for (int k = j + 1 + FAST; k < NB; ++k) lk[k] = colbuf[j][k];
   }
-  return my_inv;
 }
 
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
@@ -524,7 +521,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
     if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
       if (i == ocol) t = col_ok ? t + lambda : 1.0;
       Dm[i][ocol] = t;
-      Tm[i][ocol] = 0.0;
+      Tm[i][ocol] = (i == ocol) ? 1.0 : 0.0;     // the T half of the diagonal workgroup carries I: X = L_d^-T for free
     } else {
       Tm[i][ocol] = t;
       double dv = (j0 + i < P && col_ok) ? aD[g] : 0.0;
@@ -541,14 +538,15 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 #pragma unroll
   for (int k = 0; k < NB; ++k) a[k] = src[row][k];
   if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
-  const double my_inv = chol_trsm_rows(a, colbuf, lane);
+  chol_trsm_rows(a, colbuf, lane);
   if (stamp) { asm volatile("" :: "v"(a[NB - 1])); stamp[4] = __builtin_amdgcn_s_memtime(); }
   if (r == j) {
-    if (lane < NB) {
-      d.ldiag_rd[(size_t)j * NB + row] = my_inv;
-      double* out = d.ldiag + ((size_t)j * NB + row) * NB;
+    if (lane >= NB) {
+      // row `row` of X = L_d^-T (upper triangular), stored k-major so that the back substitution's lane i reads
+      // its row with coalesced loads: ldiag[j][k][i] = X[i][k]
+      double* out = d.ldiag + (size_t)j * NB * NB + row;
 #pragma unroll
-      for (int k = 0; k < NB; ++k) out[k] = (k <= row) ? a[k] : 0.0;
+      for (int k = 0; k < NB; ++k) out[k * NB] = (k >= row) ? a[k] : 0.0;
     }
   } else if (lane >= NB) {
     if (is_rhs) {
@@ -600,15 +598,16 @@ __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
     for (int i = tid; i < ld; i += blockDim.x) ylds[i] = yg[i];
   }
   auto yref = [&](int i) -> double& { return Y_LDS ? ylds[i] : yg[i]; };
-  // wave 0 owns the triangular solves (lane i = column i of L_d, static register indexing, reciprocal
-  // diagonal from the factorisation); waves 1-3 fold x_b into the y of the blocks above, their 32
-  // independent coalesced row loads per thread issued before x_b exists
-  double col[NB], rdi = 1.0;
+  // wave 0 owns the diagonal blocks: x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the
+  // factorisation left in ldiag (lane i holds row i, static register indexing; no sequential column chain);
+  // waves 1-3 fold x_b into the y of the blocks above, their 32 independent coalesced row loads per thread
+  // issued before x_b exists
+  __shared__ double yb[NB];
+  double col[NB];
   if (tid < 64) {
-    const double* Ld = d.ldiag + (size_t)(nbk - 1) * NB * NB;
+    const double* Xd = d.ldiag + (size_t)(nbk - 1) * NB * NB;
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];      // column `lane` of L_d (zero above the diagonal)
-    rdi = d.ldiag_rd[(size_t)(nbk - 1) * NB + lane];
+    for (int k = 0; k < NB; ++k) col[k] = Xd[k * NB + lane];      // row `lane` of L_d^-T
   }
   __syncthreads();
   unsigned long long* stamp = (d.stamps && tid == 0) ? d.stamps + 128 : nullptr;
@@ -627,24 +626,22 @@ __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
         }
       }
     } else {
-      double yi = (c0 + lane < P) ? yref(c0 + lane) : 0.0;
-      double xi = 0.0;
+      if (tid < NB) yb[lane] = (c0 + lane < P) ? yref(c0 + lane) : 0.0;      // single wave: LDS in order
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
 #pragma unroll
-      for (int jj = NB - 1; jj >= 0; --jj) {
-        const double xj = lane_bcast(yi * rdi, jj);
-        xi = (lane == jj) ? xj : xi;
-        yi -= col[jj] * xj;              // lanes >= jj: col[jj] multiplies a value no longer used
+      for (int k = 0; k < NB; k += 4) {
+        x0 += col[k] * yb[k]; x1 += col[k + 1] * yb[k + 1]; x2 += col[k + 2] * yb[k + 2]; x3 += col[k + 3] * yb[k + 3];
       }
+      const double xi = (x0 + x1) + (x2 + x3);
       if (tid < NB) {
         xb[lane] = (c0 + lane < P) ? xi : 0.0;
         if (c0 + lane < P) d.delta[c0 + lane] = xi;
       }
       if (stamp) stamp[4 * b + 1] = __builtin_amdgcn_s_memtime();
       if (b > 0) {                       // next diagonal factor; lands during the update below
-        const double* Ld = d.ldiag + (size_t)(b - 1) * NB * NB;
+        const double* Xd = d.ldiag + (size_t)(b - 1) * NB * NB;
 #pragma unroll
-        for (int jj = 0; jj < NB; ++jj) col[jj] = Ld[jj * NB + lane];
-        rdi = d.ldiag_rd[(size_t)(b - 1) * NB + lane];
+        for (int k = 0; k < NB; ++k) col[k] = Xd[k * NB + lane];
       }
     }
     __syncthreads();
@@ -908,7 +905,6 @@ static int ba_create_impl(int V, int N, int64_t M, const int* pt_ptr, const int*
   BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
   BA_ALLOC(d.delta, (size_t)d.ld);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
-  BA_ALLOC(d.ldiag_rd, (size_t)((d.P + 31) / 32) * 32);
   BA_ALLOC(d.status, 2);
 #undef BA_ALLOC
   d.red = p->own_red;
@@ -946,7 +942,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.ldiag_rd, d.status, p->schur_ws, p->schur_blk_ptr};
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_blk_ptr};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
