@@ -617,12 +617,13 @@ __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
     if (stamp) stamp[4 * b + 0] = __builtin_amdgcn_s_memtime();
     double v[2][NB];
     if (tid >= 64) {
+      // this thread's two ADJACENT rows 2 utid, 2 utid + 1 as one 16-byte load per k (half the requests of
+      // two 8-byte loads: the hand-over to wave 0 waits for exactly these loads)
+      if (2 * utid < c0) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = utid + h * 192;
-        if (i < c0) {
-#pragma unroll
-          for (int k = 0; k < NB; ++k) v[h][k] = S[(size_t)(c0 + k) * ld + i];   // rows >= P are zero (memset, never written)
+        for (int k = 0; k < NB; ++k) {
+          const double2 t = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + k) * ld + 2 * utid]);   // rows >= P are zero
+          v[0][k] = t.x; v[1][k] = t.y;
         }
       }
     } else {
@@ -647,15 +648,12 @@ __global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
     __syncthreads();
     if (stamp) stamp[4 * b + 2] = __builtin_amdgcn_s_memtime();
     if (tid >= 64) {
+      if (2 * utid < c0) {
+        double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = utid + h * 192;
-        if (i < c0) {
-          double s = 0;
-#pragma unroll
-          for (int k = 0; k < NB; ++k) s += v[h][k] * xb[k];
-          yref(i) -= s;
-        }
+        for (int k = 0; k < NB; ++k) { s0 += v[0][k] * xb[k]; s1 += v[1][k] * xb[k]; }
+        yref(2 * utid) -= s0;
+        yref(2 * utid + 1) -= s1;
       }
       if (BIG) back_solve_far_rows<Y_LDS>(S, ld, c0, utid, xb, Y_LDS ? ylds : yg);
     }
