@@ -178,6 +178,11 @@ __global__ void jac_pt_kernel(int n, int n_views, const double* projs, const dou
 // ---------------------------------------------------------------------------------------------
 constexpr int kTriLdsViews = 512;
 
+// NV > 0: the view count is a compile-time constant (2..4, the pipeline's case is 2) and the point's keys stay
+// in registers for all iterations -- re-reading them made the kernel L2/HBM-bound (4.8 GB for 10^6 points x 3
+// views x 100 iterations).  NV == 0: any number of views, keys re-read per iteration.  One division per view
+// and iteration (iz = 1 / s2 serves the residual and the Jacobian).
+template <int NV>
 __global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, const double* __restrict__ projs,
                                                             const double* __restrict__ uv,
                                                             const double* __restrict__ Xin, double lambda, int iters,
@@ -193,15 +198,26 @@ __global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, 
   if (p >= m) return;
   double x0 = Xin[p], x1 = Xin[(size_t)m + p], x2 = Xin[2 * (size_t)m + p];
   const double x3 = Xin[3 * (size_t)m + p];
+  constexpr int NC = NV > 0 ? NV : 1;
+  double ku[NC], kv[NC];
+  if (NV > 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { ku[v] = uv[((size_t)v * 2 + 0) * m + p]; kv[v] = uv[((size_t)v * 2 + 1) * m + p]; }
+  }
   for (int it = 0; it < iters; ++it) {
     double a00 = 0, a10 = 0, a11 = 0, a20 = 0, a21 = 0, a22 = 0, b0 = 0, b1 = 0, b2 = 0;
-    for (int v = 0; v < n_views; ++v) {
-      const double* P = P_all + 12 * v;
+    auto view = [&](const double* P, double ku_v, double kv_v) {
       double s[3], j[6];
+#pragma unroll
       for (int r = 0; r < 3; ++r) s[r] = P[4 * r] * x0 + P[4 * r + 1] * x1 + P[4 * r + 2] * x2 + P[4 * r + 3] * x3;
-      jac_pt(P, s, j);
-      const double eu = s[0] / s[2] - uv[((size_t)v * 2 + 0) * m + p];
-      const double ev = s[1] / s[2] - uv[((size_t)v * 2 + 1) * m + p];
+      const double iz = rcp_nr(s[2]), iz2 = iz * iz;       // v_rcp_f64 + two Newton steps (a true division is ~2x the instructions)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {                       // tri:261-269
+        j[c] = (s[2] * P[c] - s[0] * P[8 + c]) * iz2;
+        j[3 + c] = (s[2] * P[4 + c] - s[1] * P[8 + c]) * iz2;
+      }
+      const double eu = s[0] * iz - ku_v;
+      const double ev = s[1] * iz - kv_v;
       a00 += j[0] * j[0] + j[3] * j[3];
       a10 += j[1] * j[0] + j[4] * j[3];
       a11 += j[1] * j[1] + j[4] * j[4];
@@ -211,6 +227,13 @@ __global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, 
       b0 += j[0] * eu + j[3] * ev;
       b1 += j[1] * eu + j[4] * ev;
       b2 += j[2] * eu + j[5] * ev;
+    };
+    if (NV > 0) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) view(P_all + 12 * v, ku[v], kv[v]);
+    } else {
+      for (int v = 0; v < n_views; ++v)
+        view(P_all + 12 * v, uv[((size_t)v * 2 + 0) * m + p], uv[((size_t)v * 2 + 1) * m + p]);
     }
     a00 += lambda; a11 += lambda; a22 += lambda;
     // symmetric 3x3 inverse by adjugate (np.linalg.inv in the reference, tri:227)
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, 
     const double c10 = a20 * a21 - a10 * a22;
     const double c20 = a10 * a21 - a20 * a11;
     const double det = a00 * c00 + a10 * c10 + a20 * c20;
-    const double id = 1.0 / det;
+    const double id = rcp_nr(det);
     const double c11 = a00 * a22 - a20 * a20;
     const double c21 = a10 * a20 - a00 * a21;
     const double c22 = a00 * a11 - a10 * a10;
@@ -230,6 +253,17 @@ __global__ __launch_bounds__(256) void tri_nonlinear_kernel(int m, int n_views, 
   Xout[(size_t)m + p] = x1;
   Xout[2 * (size_t)m + p] = x2;
   Xout[3 * (size_t)m + p] = x3;
+}
+
+static void launch_tri_nonlinear(int m, int n_views, const double* projs, const double* uv, const double* Xin, double lambda,
+                                 int iters, double* Xout, size_t lds, hipStream_t s) {
+  const dim3 grid((m + 255) / 256), block(256);
+  switch (n_views) {
+    case 2: tri_nonlinear_kernel<2><<<grid, block, lds, s>>>(m, n_views, projs, uv, Xin, lambda, iters, Xout); break;
+    case 3: tri_nonlinear_kernel<3><<<grid, block, lds, s>>>(m, n_views, projs, uv, Xin, lambda, iters, Xout); break;
+    case 4: tri_nonlinear_kernel<4><<<grid, block, lds, s>>>(m, n_views, projs, uv, Xin, lambda, iters, Xout); break;
+    default: tri_nonlinear_kernel<0><<<grid, block, lds, s>>>(m, n_views, projs, uv, Xin, lambda, iters, Xout); break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -816,7 +850,7 @@ int sfm_tri_nonlinear(int m, int n_views, const double* projs, const double* uv,
   SFM_TRY(dX.upload(X_in, 4 * (size_t)m, s));
   SFM_TRY(dO.alloc(4 * (size_t)m));
   const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
-  tri_nonlinear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dX.p, lambda, iters, dO.p);
+  launch_tri_nonlinear(m, n_views, dP.p, dUV.p, dX.p, lambda, iters, dO.p, lds, s);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
   SFM_HIP(hipStreamSynchronize(s));
@@ -854,7 +888,7 @@ int sfm_triangulate(int m, int n_views, const double* projs, const double* uv, d
   SFM_TRY(dL.alloc(4 * (size_t)m)); SFM_TRY(dO.alloc(4 * (size_t)m));
   const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
   tri_linear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dL.p);          // tri:85
-  tri_nonlinear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dL.p, lambda, iters, dO.p);   // tri:86
+  launch_tri_nonlinear(m, n_views, dP.p, dUV.p, dL.p, lambda, iters, dO.p, lds, s);   // tri:86
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
   SFM_HIP(hipStreamSynchronize(s));
