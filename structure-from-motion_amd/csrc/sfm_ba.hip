@@ -42,7 +42,7 @@ __device__ __forceinline__ void obs_terms(const CamPrep& c, double X, double Y, 
                                           int quirks, double* r, double* Jp, double* Jx) {
   double p[3];
   project_cam(c, X, Y, Z, 1.0, p);
-  const double iz = 1.0 / p[2];          // one division per observation; f = p * iz (ba:339-342)
+  const double iz = rcp_nr(p[2]);        // one reciprocal (v_rcp_f64 + two Newton steps) per observation; f = p * iz (ba:339-342)
   jac_cam_iz(c, X, Y, Z, p, iz, quirks, Jp);
   jac_pt_cam_iz(c, p, iz, Jx);
   r[0] = u - p[0] * iz;        // b - f (ba:376)

@@ -382,7 +382,7 @@ __device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
     double d = a[j * (j + 1) / 2 + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= a[j * (j + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
-    inv[j] = 1.0 / sqrt(d);
+    inv[j] = rsqrt_nr(d);
     a[j * (j + 1) / 2 + j] = d * inv[j];
 #pragma unroll
     for (int i = j + 1; i < 7; ++i) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
     auto accumulate = [&](const double (&pt)[6], int p) {
       double pc[3], jp[14];
       project_cam(c, pt[0], pt[1], pt[2], pt[3], pc);
-      const double iz = 1.0 / pc[2];
+      const double iz = rcp_nr(pc[2]);
       jac_cam_iz(c, pt[0], pt[1], pt[2], pc, iz, quirks, jp);
       const double eu = pt[4] - pc[0] * iz, ev = pt[5] - pc[1] * iz;
       const bool use_v = !(quirks & SFM_Q1_PNP_ROW_OVERLAP) || (p == n - 1);
