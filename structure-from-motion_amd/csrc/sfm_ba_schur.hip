@@ -321,7 +321,7 @@ __host__ __device__ inline SchurTileRef plan_locate(const SchurPlan& pl, int w) 
 // One workgroup = (tile (A, B), chunk of points), 16 waves; a wave takes a point, finds its observations in
 // block A and in block B through the per-point block offsets (blk_ptr, built at plan time; the observations
 // of a point are sorted by camera, so a block is a contiguous sub-range) and multiplies their Z blocks (AoS,
-// 168 B each, read straight from L2); every product is one ds_add_f64 into the tile.  No global atomics: the
+// 168 B each, read straight from L2 / the scalar cache); every product is one ds_add_f64 into the tile.  No global atomics: the
 // tile goes to its slab and ba_schur_reduce sums the
 // slabs exactly as for the dense path.  Work is proportional to sum_p k_p (k_p + 1) / 2 (sparse-optimal).
 // ---------------------------------------------------------------------------------------------
@@ -331,17 +331,10 @@ constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubl
 constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP;
 
 // One (point, tile) visit by one wave.  Lanes = (observation b of block B, column j): each keeps its three
-// Z values and its tile column in registers.  The A side is loaded in ONE batch: register slot a of lanes
-// 0..20 holds the 21 values of observation a (all <= 18 loads in flight together, a single memory latency per
-// visit instead of one per observation); the wave then walks the slots, reads row i's three values with
-// v_readlane (constant lane, constant slot) and issues one ds_add_f64 per lane and row.  The block offsets of
-// the wave's NEXT point are fetched before the current visit is computed.
-__device__ __forceinline__ double lane_value(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
+// Z values and its tile column in registers.  The A side is wave-uniform: the wave walks the observations a of
+// block A, their 21 values arrive through the scalar data cache (s_load from the constant address space) and
+// feed the FMAs as scalar operands; one ds_add_f64 per lane and row.  The visit's B side and camera slots are
+// loaded one visit ahead and the block offsets two visits ahead (software pipeline over the wave's points).
 template <bool DIAG>
 __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __restrict__ blk_ptr, int nblk, int ti, int tj,
                                                 int p_beg, int p_end, double* __restrict__ slab, double* __restrict__ tile) {
@@ -351,6 +344,8 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
   for (int t = tid; t < nr * TP; t += PAIR_THREADS) tile[t] = 0.0;
   __syncthreads();
   const double* __restrict__ Z = d.Z;
+  typedef const __attribute__((address_space(4))) double ConstF64;
+  ConstF64* Zc = (ConstF64*)d.Z;
   const int* __restrict__ cam_idx = d.cam_idx;
   // lanes 0..3 fetch bp[ti], bp[ti+1], bp[tj], bp[tj+1] of a point
   auto fetch_bp = [&](int p) -> int {
@@ -362,7 +357,6 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
   // and camera slots one visit ahead, products now -- the memory latency of a visit hides behind the previous one.
   struct Visit {
     int a0, kA, b0, kB;
-    double za[CB];             // slot a, lanes 0..20: Z block of observation a0 + a
     int ca_lane;               // lanes 0..kA-1: tile row offset of camera slot a
     double zb0, zb1, zb2;      // first lane round of the B side
     int col;                   // its tile column (or -1)
@@ -371,9 +365,6 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
     v.a0 = __builtin_amdgcn_readlane(bp, 0); v.kA = __builtin_amdgcn_readlane(bp, 1) - v.a0;
     v.b0 = __builtin_amdgcn_readlane(bp, 2); v.kB = __builtin_amdgcn_readlane(bp, 3) - v.b0;
     if (v.kA <= 0 || v.kB <= 0) { v.kA = 0; return; }
-    const int zl = lane < 21 ? lane : 20;
-#pragma unroll
-    for (int a = 0; a < CB; ++a) v.za[a] = (a < v.kA) ? Z[(size_t)(v.a0 + a) * 21 + zl] : 0.0;
     v.ca_lane = 7 * TP * (cam_idx[v.a0 + (lane < v.kA ? lane : 0)] - ti * CB);
     const bool on = lane < 7 * v.kB;
     const int b = on ? lane / 7 : 0, j = lane - 7 * b;
@@ -388,9 +379,12 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
       if (a < v.kA) {                                      // wave-uniform
         double* trow = tcol + __builtin_amdgcn_readlane(v.ca_lane, a);
         const bool mine = col >= 0 && (!DIAG || b <= a);   // lower part of a diagonal tile only
+        // the A side is wave-uniform: its 21 values come through the scalar data cache straight into SGPRs
+        // (constant address space: Z is not written while this kernel runs) and feed the FMAs as scalar operands
+        const ConstF64* za = Zc + (size_t)(v.a0 + a) * 21;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-          const double val = lane_value(v.za[a], 3 * i) * zb0 + lane_value(v.za[a], 3 * i + 1) * zb1 + lane_value(v.za[a], 3 * i + 2) * zb2;
+          const double val = za[3 * i] * zb0 + za[3 * i + 1] * zb1 + za[3 * i + 2] * zb2;
           if (mine) atomicAdd(trow + i * TP, val);
         }
       }
