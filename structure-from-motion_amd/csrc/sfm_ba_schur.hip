@@ -621,7 +621,10 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     pl = make_pairs_plan(d);
     const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);
-    ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, kPairLdsBytes, s>>>(d, p->schur_blk_ptr, ws, pl);
+    // a scene with fewer than 18 cameras uses only part of the tile: a smaller LDS footprint lets several
+    // workgroups share a CU (small scenes are latency-bound)
+    const size_t lds = sizeof(double) * (size_t)7 * std::min(CB, d.V) * TP;
+    ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, lds, s>>>(d, p->schur_blk_ptr, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
   }
   const int ntiles = pl.n_off + pl.nblk;
