@@ -4,7 +4,7 @@
 out=gpurun_out/ab; mkdir -p $out
 lib=structure-from-motion_amd/libsfm_hip.so
 cp $lib /tmp/keep.so
-for rep in 1 2; do
+for rep in ${AB_REPS:-1 2}; do
   for v in ${AB_VARIANTS:-old new}; do
     cp gpurun_ab/$v.so $lib
     timeout -k 10 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > $out/$v.$rep.log 2>&1 || exit 1
