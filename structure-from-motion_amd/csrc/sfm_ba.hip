@@ -564,10 +564,11 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 }
 
 // L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one workgroup:
-// per block one wave solves the 32x32 upper-triangular system with lane i holding column i of L_d
-// (static register indexing; the next block's column is prefetched while all threads fold x_b into
-// the y of the blocks above, 32 independent coalesced loads per thread).  Then the camera update of
-// ba:383-392 and the preparation of the next iteration.
+// per block, wave 0 computes x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the factorisation left
+// in ldiag (lane i holds row i; the next block's factor is prefetched) while the other waves hold the L rows of
+// the blocks above in registers (two adjacent rows per thread, 32 independent 16-byte loads issued before x_b
+// exists) and fold x_b into their y.  Then the camera update of ba:383-392 and the preparation of the next
+// iteration.
 // Rows beyond the 384 that ba_back_solve's update waves hold in registers; only the BIG instantiation
 // (7V > 416) contains it, so the small-system kernel keeps its register allocation.
 template <bool Y_LDS>
