@@ -65,6 +65,51 @@ def test_append_rejects_bad_input(hip, sfm):
         assert np.array_equal(cams, sc.cams_init) and np.array_equal(pts, sc.pts_init)
 
 
+@pytest.mark.parametrize("shape", [(50, 4000, 0.6, "mfma"), (200, 3000, 0.15, "pairs"), (40, 2500, 0.3, "auto")])
+def test_two_rank_emulation_on_one_gpu_equals_single_problem(hip, sfm, shape):
+    """The multi-GPU decomposition on the real HIP path: two point shards as two resident problems on one GPU,
+    their partial [S | rhs] summed by hand where RCCL's all-reduce would sit (sharding.ShardedBa), every "rank"
+    solving the same reduced system and back-substituting its own points -- against the unsharded problem."""
+    import torch
+    n_cams, n_pts, vis, schur = shape
+    sh = sfm.sharding
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=31)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    mode = {"mfma": hip.SCHUR_MFMA, "pairs": hip.SCHUR_PAIRS, "auto": hip.SCHUR_AUTO}[schur]
+    bounds = sh.shard_bounds(sc.pt_ptr, 2)
+    assert 0 < bounds[1] < n_pts
+    engines, ranges = [], []
+    try:
+        for r in range(2):
+            ptr_l, cam_l, uv_l, pts_l, rng = sh.local_shard(sc.pt_ptr, sc.cam_idx, uvn, sc.pts_init, bounds, r)
+            eng = sh.HipShardEngine(n_cams, ptr_l, cam_l, uv_l, torch.device("cuda", 0))
+            eng.prob.set_option(hip.OPT_SCHUR, mode)
+            eng.set_state(sc.cams_init, pts_l)
+            engines.append(eng); ranges.append(rng)
+        torch.cuda.synchronize()
+        with engines[-1].stream_context():            # the library launches on the stream of the engine created last
+            for _ in range(3):
+                bufs = [e.linearize_reduce(5.0) for e in engines]
+                total = bufs[0] + bufs[1]               # <- all_reduce(SUM)
+                for b in bufs:
+                    b.copy_(total)
+                for e in engines:
+                    e.solve_update(5.0)
+        states = [e.get_state() for e in engines]
+    finally:
+        for e in engines:
+            e.close()
+    assert np.array_equal(states[0][0], states[1][0])   # identical reduced system -> identical cameras on both ranks
+    pts = np.hstack((states[0][1], states[1][1]))
+    with hip.BaProblem(n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, mode)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 3)
+        cams_f, pts_f = prob.get_state()
+    assert np.max(np.abs(states[0][0] - cams_f)) < 1e-10 * max(1.0, np.max(np.abs(cams_f)))
+    assert np.max(np.abs(pts - pts_f)) < 1e-10 * np.max(np.abs(pts_f))
+
+
 def test_incremental_growth_matches_oracle(hip, sfm, oracle):
     """View-by-view growth with BA after every registration (BASELINE config 5 stand-in), the scene resident on
     the device throughout, against the oracle's block-sparse BA on the same sequence of structures."""
