@@ -8,10 +8,15 @@
 
 A "step" is one damped Gauss-Newton iteration (ba_processor.py:297-406): linearise all
 observations, form the Schur-reduced camera system, solve it, update cameras, back-substitute
-points.  Inputs are resident in HBM before the timed region.  For N > 1 the scene is weak-scaled:
-50 cameras x (20 000 N) points, each rank owns a contiguous ~20 000-point shard and one RCCL
-all-reduce of [S | rhs] (0.99 MB) per iteration joins them; `value` counts 20 000-point
-shard-iterations per second over all ranks (= N x global iterations/s).
+points.  Inputs are resident in HBM before the timed region.
+
+  --config C3 (default, the headline): for N > 1 the scene is WEAK-scaled: 50 cameras x (20 000 N) points,
+      each rank owns a contiguous ~20 000-point shard and one RCCL all-reduce of [S | rhs] per iteration
+      joins them; `value` counts 20 000-point shard-iterations per second over all ranks (= N x global
+      iterations/s).
+  --config C4 (BASELINE config 4): STRONG-scaled: the 200-camera x 100 000-point scene is fixed, its
+      points are split over the N ranks by sharding.shard_bounds (balanced by camera pairs); `value` is
+      global LM iterations per second of that one scene, "scaling": "strong".
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, hipEvent-timed inside the timed
 region) and `cpu_baseline` (the NumPy block-sparse oracle on the host cores, N = 1 only).
@@ -29,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD spec; v_mfma_f64_16x16x4 measured 77.8, profiles/microbench_fp64_r01.txt)
+LDS_ADD_PEAK_TADDS = 4.8    # ds_add_f64, conflict-free, all 256 CUs (profiles/microbench_fp64_r01.txt; 2.4 at random addresses)
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
 LAMBDA = 5.0                # reference default damping_factor (ba_processor.py:24)
 
@@ -40,12 +46,72 @@ def algorithmic_costs(n_cams, pt_ptr, n_obs):
     p = 7 * n_cams
     return {
         "linearize": dict(bound="hbm", bytes=20.0 * n_obs + 28.0 * n_pts, flops=567.0 * n_obs + 60.0 * n_pts),
-        "schur": dict(bound="mfma", flops=float(np.sum(294.0 * k * (k - 1) / 2 + 168.0 * k)), bytes=168.0 * n_obs),
+        "schur": dict(bound="mfma", flops=float(np.sum(294.0 * k * (k - 1) / 2 + 168.0 * k)), bytes=168.0 * n_obs,
+                      lds_adds=float(np.sum(49.0 * k * (k - 1) / 2 + 28.0 * k))),      # one ds_add_f64 per lower-triangle entry of every camera pair
         "solve": dict(bound="mfma", flops=p ** 3 / 3.0 + 2.0 * p * p, bytes=8.0 * p * p),
         "backsub": dict(bound="hbm", bytes=20.0 * n_obs + 52.0 * n_pts, flops=300.0 * n_obs + 60.0 * n_pts),
         "prep": dict(bound="hbm", bytes=56.0 * n_cams + 152.0 * n_cams, flops=100.0 * n_cams),
         "reduce": dict(bound="hbm", bytes=8.0 * (p * p / 2.0 + p), flops=0.0),     # [S | rhs] written once
     }
+
+
+def drop_in_path(sfm, scene):
+    """What BaProcessor.process sees (ba_processor.py:267): `_BaProcessor__execute_bundle_adjustment` of the drop-in
+    class on duck-typed views / track tables of this scene, the reference's default 3 iterations.  First call =
+    observation list from the track tables + upload + solve; repeat calls = the scene is resident, only the 7 V
+    camera doubles go up.  Wall-clock on the host, PCIe and Python included; never used as `value`."""
+    n_views = scene.n_cams
+
+    class KP:
+        __slots__ = ("pt",)
+
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class View:
+        def __init__(self, rot, loc, k, kps):
+            self.rot, self.loc, self.k, self.key_pts = rot, loc, k, kps
+
+        def update_cam_pose(self, rot, loc):
+            self.rot, self.loc = rot, loc
+
+    class SelfRow:      # stands in for KeyTrack.table (n_views x n_keys): the BA path only ever reads row `v`
+        def __init__(self, v, row):
+            self.v, self.row = v, row
+
+        def __getitem__(self, idx):
+            assert idx[0] == self.v
+            return self.row[idx[1]]
+
+    class Holder:
+        pass
+
+    views, tracks = [], []
+    rots = sfm.geometry.quaternions_to_rotations(scene.cams_init[:, 3:7])
+    for c in range(n_views):
+        sel = np.flatnonzero(scene.cam_idx == c)
+        kps = [KP(-1.0, -1.0)] + [KP(float(scene.uv_pix[0, o]), float(scene.uv_pix[1, o])) for o in sel]
+        row = np.full(len(kps), -1, dtype=np.int64)
+        row[1:] = scene.pt_idx[sel]
+        tr = Holder(); tr.table = SelfRow(c, row)
+        tracks.append(tr)
+        views.append(View(rots[c].copy(), scene.cams_init[c, 0:3].reshape(3, 1).copy(), scene.intrinsic.copy(), kps))
+    vp, kt, tp = Holder(), Holder(), sfm.processors.HipTriangulationProcessor()
+    vp.view_list, kt.track_list = views, tracks
+    tp.tri_pts = np.vstack((scene.pts_init, np.ones((1, scene.n_pts))))
+    bp = sfm.processors.HipBaProcessor(vp, kt, None, tp, None, iteration=3, damping_factor=LAMBDA)
+    bp.ba_verbose = False
+    times, uploads, actions = [], [], []
+    for _ in range(5):
+        before = bp.ba_upload_bytes
+        t0 = time.perf_counter()
+        bp._BaProcessor__execute_bundle_adjustment()
+        times.append(time.perf_counter() - t0)
+        uploads.append(bp.ba_upload_bytes - before)
+        actions.append(bp.ba_last_action)
+    bp.ba_release()
+    return {"first_call_s": times[0], "repeat_call_s": float(np.median(times[1:])), "actions": actions,
+            "upload_bytes_first_call": uploads[0], "upload_bytes_repeat_call": uploads[1], "iterations_per_call": 3}
 
 
 def main():
@@ -82,10 +148,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    # ---- workload: weak-scaled C3 ------------------------------------------------------------
+    # ---- workload: C3 weak-scaled (points per rank fixed), C4 strong-scaled (scene fixed) --------------
     cfg = dict(sfm.scenes.CONFIGS[args.config])
+    strong = args.config == "C4" and args.pts is None
     pts_per_rank = args.pts or cfg["n_pts"]
-    scene = sfm.scenes.make_scene(cfg["n_cams"], pts_per_rank * world, cfg["visibility"], seed=0)
+    total_pts = cfg["n_pts"] if strong else pts_per_rank * world
+    scene = sfm.scenes.make_scene(cfg["n_cams"], total_pts, cfg["visibility"], seed=0)
     uvn = sfm.geometry.normalise_pixels(scene.uv_pix, scene.intrinsic)
     bounds = sfm.sharding.shard_bounds(scene.pt_ptr, world)
     ptr_l, cam_l, uv_l, pts_l, (p0, p1) = sfm.sharding.local_shard(scene.pt_ptr, scene.cam_idx, uvn, scene.pts_init, bounds, rank)
@@ -156,35 +224,49 @@ def main():
         achieved = c["bytes"] / (dom_avg_ms * 1e-3) / 1e9
         roofline = dict(kernel="ba_" + dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=achieved / HBM_PEAK_GBS)
+    # which Schur product the library launched is asked of the library, not guessed from the flags
+    schur_kernel = "ba_schur_mfma" if engine.prob.info(native.INFO_SCHUR_KERNEL) == native.SCHUR_MFMA else "ba_schur_pairs"
     if dominant == "schur":      # the product kernel alone is bracketed (ba_schur_reduce is its own class)
-        roofline["kernel"] = "ba_schur_pairs" if args.schur == "pairs" or args.config != "C3" else "ba_schur_mfma"
+        roofline["kernel"] = schur_kernel
+        if schur_kernel == "ba_schur_pairs":     # no MFMA in it: every product is one ds_add_f64 into the LDS tile
+            achieved = c["lds_adds"] / (dom_avg_ms * 1e-3) / 1e12
+            roofline.update(bound="lds", achieved=achieved, peak=LDS_ADD_PEAK_TADDS, unit="Tadd/s", frac=achieved / LDS_ADD_PEAK_TADDS)
     roofline["avg_launch_ms"] = dom_avg_ms
     roofline["launches"] = dom_n
+    # HBM bytes per launch from rocprofv3 --pmc passes (tools/parse_pmc.py), keyed by workload and kernel:
+    # profiles/traffic.json = {"<workload key>": {"<kernel>": bytes, ...}}; null when no record matches this run
+    workload_key = "%s/%dcams_%dpts_per_rank/%s" % (args.config, scene.n_cams, int(ptr_l.shape[0]) - 1, schur_kernel)
     roofline["traffic"] = None
-    tfile = os.path.join(REPO, "profiles", "traffic.json")     # HBM bytes per launch from rocprofv3 --pmc passes
+    tfile = os.path.join(REPO, "profiles", "traffic.json")
+    traffic_rec = None
     if os.path.exists(tfile):
-        try:      # a kernel class may be several kernels (schur = schur_mfma + schur_reduce, solve = chol_step x11 + back_solve)
-            tj = json.load(open(tfile))
-            prefix = {"solve": ("ba_chol_step", "ba_back_solve"), "schur": ("ba_schur_mfma", "ba_schur_pairs"),
-                      "reduce": ("ba_schur_reduce",)}.get(dominant, ("ba_" + dominant,))
-            per = {k: v for k, v in tj.items() if k.startswith(prefix) and isinstance(v, (int, float))}
-            if per:
-                mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32}
-                roofline["traffic"] = sum(v * mult.get(k, 1) for k, v in per.items())
-                roofline["traffic_unit"] = "HBM bytes per iteration of this kernel class (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)"
+        try:
+            traffic_rec = json.load(open(tfile)).get(workload_key)
         except Exception:
-            pass
+            traffic_rec = None
+    if traffic_rec:
+        kernels = {"solve": ("ba_solve", "ba_chol_step", "ba_back_solve"), "schur": (schur_kernel,),
+                   "reduce": ("ba_schur_reduce",)}.get(dominant, ("ba_" + dominant,))
+        per = {k: v for k, v in traffic_rec.items() if k.startswith(kernels) and isinstance(v, (int, float))}
+        if per:
+            mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32}
+            roofline["traffic"] = sum(v * mult.get(k, 1) for k, v in per.items())
+            roofline["traffic_unit"] = "HBM bytes per iteration of this kernel class (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json[%r])" % workload_key
 
     out = {
         "metric": "BA LM-iterations/sec + final reprojection RMSE, 50 cams x 20k pts",
-        "value": world * args.steps / elapsed,
-        "unit": "LM-iterations/s (50cam x 20k-pt shard-iterations, all ranks)",
+        "value": (1 if strong else world) * args.steps / elapsed,
+        "unit": ("LM-iterations/s of the one 200cam x 100k-pt scene (points split over the ranks)" if strong else
+                 "LM-iterations/s (50cam x 20k-pt shard-iterations, all ranks)"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s: %d cams x %d pts/rank @ %.0f%% visibility, lambda=5, Schur BA" % (
-            args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"]),
+        "config": {"workload": ("%s: %d cams x %d pts in total @ %.0f%% visibility, strong-scaled: %d..%d pts per rank, lambda=5, Schur BA" % (
+                                    args.config, scene.n_cams, scene.n_pts, 100 * cfg["visibility"],
+                                    int(np.min(np.diff(bounds))), int(np.max(np.diff(bounds))))) if strong else
+                               ("%s: %d cams x %d pts/rank @ %.0f%% visibility, lambda=5, Schur BA" % (
+                                    args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"])),
             "observations_per_rank": int(cam_l.shape[0]), "points_total": int(scene.n_pts),
             "parallelism": "points sharded x%d, cameras replicated, all-reduce [S|rhs]" % world if world > 1 else "single GPU",
             "schur": args.schur},
@@ -201,16 +283,26 @@ def main():
     out["hbm"] = {"algorithmic_bytes_per_iteration": alg_bytes, "algorithmic_GBps": alg_bytes / iter_s / 1e9,
                   "algorithmic_frac_of_peak": alg_bytes / iter_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
                   "measured_bytes_per_iteration": None}
-    if os.path.exists(tfile) and args.config == "C3" and args.schur == "auto":
-        try:
-            tj = json.load(open(tfile))
-            mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32, "ba_cam_prep": 0}
-            meas = sum(v * mult.get(k, 1) for k, v in tj.items() if k.startswith("ba_") and isinstance(v, (int, float)))
-            out["hbm"].update({"measured_bytes_per_iteration": meas, "measured_GBps": meas / iter_s / 1e9,
-                               "measured_frac_of_peak": meas / iter_s / 1e9 / HBM_PEAK_GBS,
-                               "measured_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel, 1-GPU C3 run)"})
-        except Exception:
-            pass
+    if traffic_rec:
+        mult = {"ba_chol_step": (7 * scene.n_cams + 31) // 32, "ba_cam_prep": 0}
+        meas = sum(v * mult.get(k, 1) for k, v in traffic_rec.items() if k.startswith("ba_") and isinstance(v, (int, float)))
+        out["hbm"].update({"measured_bytes_per_iteration": meas, "measured_GBps": meas / iter_s / 1e9,
+                           "measured_frac_of_peak": meas / iter_s / 1e9 / HBM_PEAK_GBS,
+                           "measured_source": "profiles/traffic.json[%r] (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel; a committed "
+                                              "record of an earlier run of this workload, not measured in this run)" % workload_key})
+
+    # ---- N > 1: every rank must hold bit-identical cameras after the redundant solves -----------------
+    if use_dist and world > 1:
+        cams_dev = torch.from_numpy(np.ascontiguousarray(cams_end)).to(device)
+        ref = cams_dev.clone()
+        dist.broadcast(ref, src=0)
+        dev = (cams_dev - ref).abs().max().reshape(1)
+        dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+        out["max_camera_deviation_across_ranks"] = float(dev.item())
+        if float(dev.item()) != 0.0:
+            if rank == 0:
+                print(json.dumps(out))
+            raise SystemExit("ranks disagree on the cameras after the replicated reduced solve: max |cams - cams(rank 0)| = %g" % float(dev.item()))
 
     # ---- CPU baseline (rank 0, N = 1): the NumPy block-sparse oracle, 3 iterations of the same scene
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -240,10 +332,10 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         # PCIe-inclusive rate of the host-buffer entry point (sfm_ba_solve: create + upload + 3 iterations +
         # download), for DESIGN.md; never used as `value`
-        native.set_stream(0)
         t0 = time.perf_counter()
         native.ba_solve(scene.n_cams, scene.pt_ptr, scene.cam_idx, uvn, scene.cams_init, scene.pts_init, LAMBDA, 3)
         out["host_buffer_path"] = {"seconds_for_3_iterations_incl_setup_and_pcie": time.perf_counter() - t0}
+        out["drop_in_path"] = drop_in_path(sfm, scene)
 
     if world > 1 or args.no_cpu_baseline:
         engine.close()

@@ -51,6 +51,14 @@ extern "C" {
 #define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps) */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
+/* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
+#define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA: the product kernel the next iteration launches */
+#define SFM_INFO_UPLOAD_BYTES  2  /* host -> device bytes moved on behalf of this handle since sfm_ba_create */
+#define SFM_INFO_N_CAMS        3
+#define SFM_INFO_N_PTS         4
+#define SFM_INFO_N_OBS         5
+#define SFM_INFO_MAX_TRACK     6  /* longest track (observations of one point) */
+
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */
 #define SFM_K_PREP       0
 #define SFM_K_LINEARIZE  1
@@ -65,8 +73,9 @@ int sfm_version(void);
 /* Select the HIP device this process drives (one process per GPU) and create the library stream. */
 int sfm_init(int device);
 int sfm_shutdown(void);
-/* Run all subsequent work on an existing HIP stream (hipStream_t as void*), e.g. torch's current
- * stream, so RCCL collectives issued by the host framework order correctly.  NULL = own stream. */
+/* Default stream of the library (hipStream_t as void*): the host-pointer entry points run on it and a new BA
+ * problem starts on it.  NULL = the library's own stream (created by sfm_init, alive until sfm_shutdown).
+ * A resident BA problem keeps the stream it was given (sfm_ba_set_stream), whatever this is set to later. */
 int sfm_set_stream(void* hip_stream);
 int sfm_synchronize(void);
 const char* sfm_last_error(void);
@@ -171,7 +180,18 @@ int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx
                   const double* uv_norm, sfm_ba_problem** out);
 int sfm_ba_destroy(sfm_ba_problem* p);
 int sfm_ba_set_option(sfm_ba_problem* p, int option, int value);
+/* Run every copy and kernel of THIS problem on an existing HIP stream (e.g. a torch stream, so that an RCCL
+ * all-reduce issued under it orders with the kernels).  Each problem has its own stream: several problems in
+ * one process do not interfere.  NULL = the library's own stream.  Synchronises the previous stream. */
+int sfm_ba_set_stream(sfm_ba_problem* p, void* hip_stream);
+/* Facts about a resident problem (SFM_INFO_*). */
+int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value);
 int sfm_ba_set_state(sfm_ba_problem* p, const double* cams /*[V][7]*/, const double* pts /*[3][N]*/);
+/* Replace only the cameras / only the points [first, first + count) of the resident state: the per-view BA call
+ * of the reference (ba_processor.py:267) re-reads poses and points that did not change since the previous
+ * call's write-back; the drop-in uploads what did. */
+int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams /*[V][7]*/);
+int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts /*[3][count]*/);
 /* Enqueue `iters` damped Gauss-Newton iterations (ba_processor.py:297-406) on the library stream. */
 int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks);
 /* Synchronise, copy the state back, and report the first device-side failure (bad rotation ...). */
@@ -180,10 +200,12 @@ int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
  * re-runs global BA (ba_processor.py:137-267).  n_new_cams cameras (indices V..)
  * and n_new_pts points (indices N..) are appended with their initial state; n_new_obs observations of ANY
  * (camera, point) pair not yet present are merged into the (point, camera)-sorted list.  The existing keys,
- * cameras and points never leave the device: only the new data and the merged index structure are uploaded,
- * a gather kernel rebuilds the key arrays, every workspace is re-planned for the new size.  The handle, its
- * options and its current state survive; an externally bound reduced buffer must be bound again (its size
- * follows V).  Blocking. */
+ * cameras and points never leave the device and ONLY the new cameras, points and observations are uploaded
+ * (SFM_INFO_UPLOAD_BYTES grows by 56 n_new_cams + 24 n_new_pts + 24 n_new_obs): the merge itself runs on the
+ * device (count / scan / bucket / merge kernels), every workspace is re-planned for the new size.  The handle,
+ * its options, stream and current state survive; an externally bound reduced buffer survives when no camera
+ * was added, otherwise the library's own buffer takes over and the caller binds a new one (its size follows
+ * V).  On error the problem is unchanged.  Blocking. */
 int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams /*[n_new_cams][7]*/, int n_new_pts,
                   const double* pts /*[3][n_new_pts]*/, int64_t n_new_obs, const int* obs_cam /*[n_new_obs]*/,
                   const int* obs_pt /*[n_new_obs]*/, const double* uv_norm /*[2][n_new_obs]*/);

@@ -12,6 +12,7 @@ namespace sfm {
 constexpr int kSchurCB = 18;
 constexpr int kSchurRB = 128;
 constexpr int kSchurKSL = 16;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
+constexpr int kLinGridPerCu = 3; // ba_linearize workgroups per CU (132 VGPRs -> 3 waves/SIMD; forcing 4 measured 10 % slower)
 
 // Plain-data view passed by value to kernels (all pointers are device memory).
 struct BaDev {
@@ -42,6 +43,7 @@ struct BaDev {
   double* delta = nullptr;  // [ld] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
   int* status = nullptr;    // [2] first failure code, camera index
+  int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
   unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };
 
@@ -78,6 +80,8 @@ constexpr unsigned kBaMagic = 0x5F3BA001u;
 struct sfm_ba_problem {
   unsigned magic = sfm::kBaMagic;
   sfm::BaDev dev;
+  hipStream_t stream = nullptr;   // every copy and kernel of this problem goes here (sfm_ba_set_stream)
+  long long upload_bytes = 0;     // host -> device bytes moved on behalf of this handle (SFM_INFO_UPLOAD_BYTES)
   int cur = 0;               // which prep slot holds the cameras of the current state
   bool prep_valid = false;
   int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
@@ -92,13 +96,12 @@ struct sfm_ba_problem {
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
   int* schur_blk_ptr = nullptr;  // [N][nblk + 1] first observation of a point in each 18-camera block (sparse path)
   bool schur_mfma_ok = false;
-  // host mirror of the static structure (sfm_ba_append merges new observations into it)
-  std::vector<int> h_pt_ptr, h_cam_idx;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 
 namespace sfm {
 int ba_schur_plan(sfm_ba_problem* p);
+int ba_enqueue_structure(sfm_ba_problem* p);      // validate the CSR, fill obs_pt / per-point block offsets / longest track (device)
 int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
@@ -106,4 +109,6 @@ bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);
+void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out);
 }  // namespace sfm

@@ -686,8 +686,6 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ S, int ld, int P
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-constexpr int kLinGridPerCu = 3;   // ba_linearize workgroups per CU (132 VGPRs -> 3 waves/SIMD; forcing 4 measured 10 % slower)
-
 static int pick_group(const sfm_ba_problem* p) {
   // lanes per point: smallest power of two >= mean track length (clamped to [4, 64]); longer tracks loop
   double mean = p->dev.N > 0 ? (double)p->dev.M / p->dev.N : 1.0;
@@ -737,7 +735,7 @@ void ba_tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
 }
 
 int ba_enqueue_prep(sfm_ba_problem* p) {
-  hipStream_t s = ctx().stream;
+  hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   ba_tick(p, SFM_K_PREP, true, s);
   ba_cam_prep_kernel<<<(d.V + 63) / 64, 64, 0, s>>>(d.V, d.cams, d.prep[p->cur], d.status);
@@ -748,7 +746,7 @@ int ba_enqueue_prep(sfm_ba_problem* p) {
 }
 
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
-  hipStream_t s = ctx().stream;
+  hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
   if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
@@ -785,7 +783,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
 }
 
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
-  hipStream_t s = ctx().stream;
+  hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   ba_tick(p, SFM_K_SOLVE, true, s);
   const int nbk = (d.P + NB - 1) / NB;
@@ -823,414 +821,16 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   return SFM_OK;
 }
 
-// sfm_ba_append: keys of the merged observation list; src >= 0 = old observation, < 0 = new observation -1 - k
-__global__ void ba_append_gather_kernel(int m, const int* __restrict__ src, const double* __restrict__ u_old,
-                                        const double* __restrict__ v_old, const double* __restrict__ u_new,
-                                        const double* __restrict__ v_new, double* __restrict__ u, double* __restrict__ v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const int s = src[i];
-  if (s >= 0) { u[i] = u_old[s]; v[i] = v_old[s]; }
-  else { u[i] = u_new[-1 - s]; v[i] = v_new[-1 - s]; }
+// parity hooks (sfm_ba_residual_jacobian / sfm_ba_reduced_system)
+void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx) {
+  const BaDev& d = p->dev;
+  ba_residual_jacobian_kernel<<<(unsigned)((d.M + 255) / 256), 256, 0, p->stream>>>(d, p->cur, quirks, d.obs_pt, r, Jp, Jx);
 }
 
-static int check_problem(const sfm_ba_problem* p) {
-  if (p == nullptr || p->magic != kBaMagic) {
-    set_error("invalid bundle-adjustment problem handle");
-    return SFM_E_HANDLE;
-  }
-  return SFM_OK;
-}
-
-static const char* status_name(int st) {
-  switch (st) {
-    case SFM_E_BAD_ROTATION: return "invalid rotation matrix";
-    case SFM_E_QW_ZERO: return "quaternion qw ~ 0";
-    case SFM_E_SQRT_DOMAIN: return "1 + trace(R) < 0";
-    default: return "unknown";
-  }
+void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out) {
+  const BaDev& d = p->dev;
+  ba_symmetrize_kernel<<<(d.P * d.P + 255) / 256, 256, 0, p->stream>>>(d.red, d.ld, d.P, lambda, S_out);
+  (void)hipMemcpyAsync(rhs_out, d.red + (size_t)d.ld * d.ld, sizeof(double) * d.P, hipMemcpyDeviceToDevice, p->stream);
 }
 
 }  // namespace sfm
-
-using namespace sfm;
-
-extern "C" {
-
-// uv_norm == nullptr: the keys are filled on the device afterwards (sfm_ba_append)
-static int ba_create_impl(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
-                          sfm_ba_problem** out) {
-  SFM_TRY(ensure_init());
-  if (out == nullptr) { set_error("sfm_ba_create: out is null"); return SFM_E_SHAPE; }
-  *out = nullptr;
-  if (V < 1 || N < 0 || M < 0 || M > 0x7fffffffLL) {
-    set_error("sfm_ba_create: bad sizes V=%d N=%d M=%lld", V, N, (long long)M);
-    return SFM_E_SHAPE;
-  }
-  if (N > 0 && (pt_ptr[0] != 0 || pt_ptr[N] != M)) { set_error("sfm_ba_create: pt_ptr must span [0, M]"); return SFM_E_SHAPE; }
-  int max_k = 0;
-  std::vector<int> obs_pt((size_t)M);
-  for (int p = 0; p < N; ++p) {
-    const int k = pt_ptr[p + 1] - pt_ptr[p];
-    if (k < 0) { set_error("sfm_ba_create: pt_ptr not monotone at point %d", p); return SFM_E_SHAPE; }
-    max_k = std::max(max_k, k);
-    for (int o = pt_ptr[p]; o < pt_ptr[p + 1]; ++o) {
-      if (cam_idx[o] < 0 || cam_idx[o] >= V) { set_error("sfm_ba_create: cam_idx[%d]=%d out of range", o, cam_idx[o]); return SFM_E_SHAPE; }
-      if (o > pt_ptr[p] && cam_idx[o] <= cam_idx[o - 1]) {
-        set_error("sfm_ba_create: observations of point %d are not sorted by strictly increasing camera", p);
-        return SFM_E_SHAPE;
-      }
-      obs_pt[o] = p;
-    }
-  }
-  sfm_ba_problem* p = new sfm_ba_problem();
-  BaDev& d = p->dev;
-  d.V = V; d.N = N; d.M = M; d.P = 7 * V;
-  d.ld = ((d.P + 63) / 64) * 64;
-  p->max_track = max_k;
-  hipStream_t s = ctx().stream;
-  auto fail = [&](int st) { sfm_ba_destroy(p); return st; };
-#define BA_ALLOC(ptr, count) do { hipError_t e_ = pool_alloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
-    if (e_ != hipSuccess) return fail(hip_fail(e_, "hipMalloc " #ptr, __LINE__)); } while (0)
-  BA_ALLOC(d.pt_ptr, (size_t)N + 1);
-  BA_ALLOC(d.cam_idx, (size_t)M);
-  BA_ALLOC(d.obs_pt, (size_t)M);
-  BA_ALLOC(d.u, (size_t)M);
-  BA_ALLOC(d.v, (size_t)M);
-  BA_ALLOC(d.cams, (size_t)V * 7);
-  BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
-  BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
-  BA_ALLOC(d.lin_ws, (sizeof(double) * V * 35 <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
-  BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
-  BA_ALLOC(d.delta, (size_t)d.ld);
-  BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
-  BA_ALLOC(d.status, 2);
-#undef BA_ALLOC
-  d.red = p->own_red;
-  const int zero_ptr = 0;
-  if (N > 0) { if (hipMemcpyAsync(d.pt_ptr, pt_ptr, sizeof(int) * ((size_t)N + 1), hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP); }
-  else { if (hipMemcpyAsync(d.pt_ptr, &zero_ptr, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP); }
-  if (M > 0) {
-    if (hipMemcpyAsync(d.cam_idx, cam_idx, sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-    if (hipMemcpyAsync(d.obs_pt, obs_pt.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-    if (uv_norm) {
-      if (hipMemcpyAsync(d.u, uv_norm, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-      if (hipMemcpyAsync(d.v, uv_norm + M, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, s) != hipSuccess) return fail(SFM_E_HIP);
-    }
-  }
-  p->h_pt_ptr.assign(pt_ptr, pt_ptr + (N > 0 ? N + 1 : 0));
-  if (N == 0) p->h_pt_ptr.assign(1, 0);
-  p->h_cam_idx.assign(cam_idx, cam_idx + M);
-  if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), s) != hipSuccess) return fail(SFM_E_HIP);
-  if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, s) != hipSuccess) return fail(SFM_E_HIP);
-  if (hipStreamSynchronize(s) != hipSuccess) return fail(SFM_E_HIP);
-  { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
-  *out = p;
-  return SFM_OK;
-}
-
-int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
-                  sfm_ba_problem** out) {
-  if (M > 0 && uv_norm == nullptr) { set_error("sfm_ba_create: uv_norm is null"); return SFM_E_SHAPE; }
-  return ba_create_impl(V, N, M, pt_ptr, cam_idx, uv_norm, out);
-}
-
-int sfm_ba_destroy(sfm_ba_problem* p) {
-  if (p == nullptr) return SFM_OK;
-  if (p->magic != kBaMagic) { set_error("sfm_ba_destroy: invalid handle"); return SFM_E_HANDLE; }
-  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
-  BaDev& d = p->dev;
-  void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, p->schur_ws, p->schur_blk_ptr};
-  for (void* q : ptrs) if (q) pool_free(q);
-  for (auto& t : p->timers)
-    for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  p->magic = 0;
-  delete p;
-  return SFM_OK;
-}
-
-int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
-  SFM_TRY(check_problem(p));
-  switch (option) {
-    case SFM_OPT_SCHUR:
-      if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
-      p->schur_mode = value;
-      return SFM_OK;
-    case SFM_OPT_DEBUG:
-      p->debug = value;
-      if ((value & 8) && p->dev.stamps == nullptr) {
-        SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
-        SFM_HIP(hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 1024));
-      }
-      return SFM_OK;
-    case SFM_OPT_TIMING:
-      p->timing = value;   // bit k set = time kernel class k
-      return SFM_OK;
-    default:
-      set_error("unknown option %d", option);
-      return SFM_E_SHAPE;
-  }
-}
-
-int sfm_ba_set_state(sfm_ba_problem* p, const double* cams, const double* pts) {
-  SFM_TRY(check_problem(p));
-  hipStream_t s = ctx().stream;
-  BaDev& d = p->dev;
-  SFM_HIP(hipMemcpyAsync(d.cams, cams, sizeof(double) * 7 * d.V, hipMemcpyHostToDevice, s));
-  if (d.N > 0) {
-    SFM_HIP(hipMemcpyAsync(d.px, pts, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
-    SFM_HIP(hipMemcpyAsync(d.py, pts + d.N, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
-    SFM_HIP(hipMemcpyAsync(d.pz, pts + 2 * (size_t)d.N, sizeof(double) * d.N, hipMemcpyHostToDevice, s));
-  }
-  SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), s));
-  SFM_HIP(hipStreamSynchronize(s));
-  p->prep_valid = false;
-  return SFM_OK;
-}
-
-int sfm_ba_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
-  SFM_TRY(check_problem(p));
-  return ba_enqueue_linearize_reduce(p, lambda, quirks);
-}
-
-int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
-  SFM_TRY(check_problem(p));
-  return ba_enqueue_solve_update(p, lambda, quirks);
-}
-
-int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks) {
-  SFM_TRY(check_problem(p));
-  if (iters < 0) { set_error("sfm_ba_iterate: iters < 0"); return SFM_E_SHAPE; }
-  for (int it = 0; it < iters; ++it) {
-    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
-    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
-  }
-  return SFM_OK;
-}
-
-int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
-  SFM_TRY(check_problem(p));
-  hipStream_t s = ctx().stream;
-  BaDev& d = p->dev;
-  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));     // validates the cameras even with zero iterations (ba:412)
-  int st[2] = {0, 0};
-  SFM_HIP(hipMemcpyAsync(cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToHost, s));
-  if (d.N > 0) {
-    SFM_HIP(hipMemcpyAsync(pts, d.px, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
-    SFM_HIP(hipMemcpyAsync(pts + d.N, d.py, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
-    SFM_HIP(hipMemcpyAsync(pts + 2 * (size_t)d.N, d.pz, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
-  }
-  SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
-  SFM_HIP(hipStreamSynchronize(s));
-  if (st[0] != SFM_OK) {
-    set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]);
-    return st[0];
-  }
-  return SFM_OK;
-}
-
-int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int n_new_pts, const double* pts_new,
-                  int64_t n_new_obs, const int* obs_cam, const int* obs_pt, const double* uv_norm) {
-  SFM_TRY(check_problem(p));
-  if (n_new_cams < 0 || n_new_pts < 0 || n_new_obs < 0) { set_error("sfm_ba_append: negative count"); return SFM_E_SHAPE; }
-  BaDev& d = p->dev;
-  const int V2 = d.V + n_new_cams, N2 = d.N + n_new_pts;
-  const long long M2 = d.M + n_new_obs;
-  if (M2 > 0x7fffffffLL) { set_error("sfm_ba_append: too many observations"); return SFM_E_SHAPE; }
-  for (long long k = 0; k < n_new_obs; ++k)
-    if (obs_cam[k] < 0 || obs_cam[k] >= V2 || obs_pt[k] < 0 || obs_pt[k] >= N2) {
-      set_error("sfm_ba_append: observation %lld = (camera %d, point %d) out of range", k, obs_cam[k], obs_pt[k]);
-      return SFM_E_SHAPE;
-    }
-  // merged structure on the host: per point the old (sorted) camera list and the new observations, by camera.
-  // src[o'] >= 0: old observation index; < 0: new observation -1 - k.
-  std::vector<int> cnt((size_t)N2 + 1, 0), new_ptr((size_t)N2 + 1, 0);
-  for (long long k = 0; k < n_new_obs; ++k) cnt[obs_pt[k]]++;
-  std::vector<int> nstart((size_t)N2 + 1, 0);
-  for (int q = 0; q < N2; ++q) nstart[q + 1] = nstart[q] + cnt[q];
-  std::vector<int> norder((size_t)n_new_obs), fill(nstart.begin(), nstart.end() - 1);
-  for (long long k = 0; k < n_new_obs; ++k) norder[fill[obs_pt[k]]++] = (int)k;
-  std::vector<int> cam2((size_t)M2), src((size_t)M2);
-  int max_k = 0;
-  long long w = 0;
-  for (int q = 0; q < N2; ++q) {
-    new_ptr[q] = (int)w;
-    int* nb = norder.data() + nstart[q];
-    int* ne = norder.data() + nstart[q + 1];
-    std::sort(nb, ne, [&](int a, int b) { return obs_cam[a] < obs_cam[b]; });
-    int o = q < d.N ? p->h_pt_ptr[q] : 0;
-    const int oe = q < d.N ? p->h_pt_ptr[q + 1] : 0;
-    while (o < oe || nb < ne) {
-      const int co = o < oe ? p->h_cam_idx[o] : 0x7fffffff;
-      const int cn = nb < ne ? obs_cam[*nb] : 0x7fffffff;
-      if (co == cn || (w > new_ptr[q] && std::min(co, cn) == cam2[w - 1])) {
-        set_error("sfm_ba_append: point %d is already observed by camera %d", q, std::min(co, cn));
-        return SFM_E_SHAPE;
-      }
-      if (co < cn) { cam2[w] = co; src[w] = o++; }
-      else { cam2[w] = cn; src[w] = -1 - *nb++; }
-      ++w;
-    }
-    max_k = std::max(max_k, (int)(w - new_ptr[q]));
-  }
-  new_ptr[N2] = (int)w;
-  (void)max_k;
-  sfm_ba_problem* q = nullptr;
-  SFM_TRY(ba_create_impl(V2, N2, M2, new_ptr.data(), cam2.data(), nullptr, &q));
-  auto fail = [&](int st) { sfm_ba_destroy(q); return st; };
-  hipStream_t s = ctx().stream;
-  BaDev& e = q->dev;
-  {
-    DevBuf<int> dsrc;
-    DevBuf<double> duv;
-    int st = dsrc.upload(src.data(), (size_t)M2, s);
-    if (st == SFM_OK) st = n_new_obs > 0 ? duv.upload(uv_norm, 2 * (size_t)n_new_obs, s) : duv.alloc(2);
-    if (st != SFM_OK) return fail(st);
-    if (M2 > 0) {
-      ba_append_gather_kernel<<<(unsigned)((M2 + 255) / 256), 256, 0, s>>>((int)M2, dsrc.p, d.u, d.v, duv.p, duv.p + n_new_obs, e.u, e.v);
-      if (hipGetLastError() != hipSuccess) return fail(SFM_E_HIP);
-    }
-    // state: old cameras / points stay on the device, the new ones are uploaded behind them
-    bool ok = hipMemcpyAsync(e.cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToDevice, s) == hipSuccess;
-    if (n_new_cams > 0) ok = ok && hipMemcpyAsync(e.cams + 7 * (size_t)d.V, cams_new, sizeof(double) * 7 * n_new_cams, hipMemcpyHostToDevice, s) == hipSuccess;
-    double* dst[3] = {e.px, e.py, e.pz};
-    const double* old[3] = {d.px, d.py, d.pz};
-    for (int k = 0; k < 3; ++k) {
-      if (d.N > 0) ok = ok && hipMemcpyAsync(dst[k], old[k], sizeof(double) * d.N, hipMemcpyDeviceToDevice, s) == hipSuccess;
-      if (n_new_pts > 0) ok = ok && hipMemcpyAsync(dst[k] + d.N, pts_new + (size_t)k * n_new_pts, sizeof(double) * n_new_pts, hipMemcpyHostToDevice, s) == hipSuccess;
-    }
-    ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    if (!ok) return fail(SFM_E_HIP);
-  }
-  // the handle keeps its identity and options; the old buffers leave with q
-  q->schur_mode = p->schur_mode; q->debug = p->debug; q->timing = p->timing; q->quirks = p->quirks;
-  std::swap(p->dev, q->dev);
-  std::swap(p->own_red, q->own_red);
-  std::swap(p->schur_ws, q->schur_ws);
-  std::swap(p->schur_blk_ptr, q->schur_blk_ptr);
-  std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
-  std::swap(p->max_track, q->max_track);
-  p->h_pt_ptr.swap(q->h_pt_ptr);
-  p->h_cam_idx.swap(q->h_cam_idx);
-  p->dev.red = p->own_red;          // a bound external reduced buffer has the wrong size now: rebind after append
-  q->dev.red = q->own_red;
-  p->cur = 0; p->prep_valid = false; p->red_clean = false; p->lin_rows = 0;
-  std::swap(p->dev.stamps, q->dev.stamps);      // the diagnostic stamp buffer stays with the handle
-  return sfm_ba_destroy(q);
-}
-
-int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {
-  SFM_TRY(check_problem(p));
-  if (device_ptr) *device_ptr = p->dev.red;
-  if (n_doubles) *n_doubles = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
-  if (ld) *ld = p->dev.ld;
-  return SFM_OK;
-}
-
-int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
-  SFM_TRY(check_problem(p));
-  const int64_t need = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
-  p->red_clean = false;
-  if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
-  if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }
-  p->dev.red = static_cast<double*>(device_ptr);
-  return SFM_OK;
-}
-
-int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches) {
-  SFM_TRY(check_problem(p));
-  if (kernel_id < 0 || kernel_id >= SFM_K_COUNT) { set_error("bad kernel id %d", kernel_id); return SFM_E_SHAPE; }
-  SFM_HIP(hipStreamSynchronize(ctx().stream));
-  KernelTimer& t = p->timers[kernel_id];
-  double tot = 0;
-  for (int i = 0; i < t.used; ++i) {
-    float ms = 0;
-    SFM_HIP(hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second));
-    tot += ms;
-  }
-  if (total_ms) *total_ms = tot;
-  if (launches) *launches = t.used;
-  return SFM_OK;
-}
-
-int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n) {
-  SFM_TRY(check_problem(p));
-  if (p->dev.stamps == nullptr || n < 0 || n > 1024) { set_error("debug stamps not enabled (SFM_OPT_DEBUG bit 8)"); return SFM_E_SHAPE; }
-  SFM_HIP(hipStreamSynchronize(ctx().stream));
-  SFM_HIP(hipMemcpy(out, p->dev.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
-  return SFM_OK;
-}
-
-int sfm_ba_reset_timing(sfm_ba_problem* p) {
-  SFM_TRY(check_problem(p));
-  SFM_HIP(hipStreamSynchronize(ctx().stream));
-  for (auto& t : p->timers) t.used = 0;
-  return SFM_OK;
-}
-
-int sfm_ba_solve(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm, double* cams,
-                 double* pts, double lambda, int iters, int quirks) {
-  sfm_ba_problem* p = nullptr;
-  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
-  int st = sfm_ba_set_state(p, cams, pts);
-  if (st == SFM_OK) st = sfm_ba_iterate(p, lambda, iters, quirks);
-  if (st == SFM_OK) st = sfm_ba_get_state(p, cams, pts);
-  sfm_ba_destroy(p);
-  return st;
-}
-
-int sfm_ba_residual_jacobian(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
-                             const double* cams, const double* pts, int quirks, double* r, double* Jp, double* Jx) {
-  sfm_ba_problem* p = nullptr;
-  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
-  auto run = [&]() -> int {
-    SFM_TRY(sfm_ba_set_state(p, cams, pts));
-    SFM_TRY(ba_enqueue_prep(p));
-    if (M == 0) return SFM_OK;
-    hipStream_t s = ctx().stream;
-    DevBuf<double> dr, djp, djx;
-    SFM_TRY(dr.alloc(2 * (size_t)M)); SFM_TRY(djp.alloc(14 * (size_t)M)); SFM_TRY(djx.alloc(6 * (size_t)M));
-    ba_residual_jacobian_kernel<<<(unsigned)((M + 255) / 256), 256, 0, s>>>(p->dev, p->cur, quirks, p->dev.obs_pt, dr.p, djp.p, djx.p);
-    SFM_HIP(hipGetLastError());
-    SFM_TRY(dr.download(r, 2 * (size_t)M, s)); SFM_TRY(djp.download(Jp, 14 * (size_t)M, s)); SFM_TRY(djx.download(Jx, 6 * (size_t)M, s));
-    int st[2] = {0, 0};
-    SFM_HIP(hipMemcpyAsync(st, p->dev.status, sizeof(st), hipMemcpyDeviceToHost, s));
-    SFM_HIP(hipStreamSynchronize(s));
-    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
-    return SFM_OK;
-  };
-  const int st = run();
-  sfm_ba_destroy(p);
-  return st;
-}
-
-int sfm_ba_reduced_system(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
-                          const double* cams, const double* pts, double lambda, int quirks, int schur_mode, double* S,
-                          double* rhs) {
-  sfm_ba_problem* p = nullptr;
-  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
-  auto run = [&]() -> int {
-    SFM_TRY(sfm_ba_set_option(p, SFM_OPT_SCHUR, schur_mode));
-    SFM_TRY(sfm_ba_set_state(p, cams, pts));
-    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
-    hipStream_t s = ctx().stream;
-    const BaDev& d = p->dev;
-    DevBuf<double> dS;
-    SFM_TRY(dS.alloc((size_t)d.P * d.P));
-    ba_symmetrize_kernel<<<(d.P * d.P + 255) / 256, 256, 0, s>>>(d.red, d.ld, d.P, lambda, dS.p);
-    SFM_HIP(hipGetLastError());
-    SFM_TRY(dS.download(S, (size_t)d.P * d.P, s));
-    SFM_HIP(hipMemcpyAsync(rhs, d.red + (size_t)d.ld * d.ld, sizeof(double) * d.P, hipMemcpyDeviceToHost, s));
-    int st[2] = {0, 0};
-    SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
-    SFM_HIP(hipStreamSynchronize(s));
-    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
-    return SFM_OK;
-  };
-  const int st = run();
-  sfm_ba_destroy(p);
-  return st;
-}
-
-}  // extern "C"

@@ -1,0 +1,586 @@
+// sfm_ba_host.hip — the device-resident bundle-adjustment problem object behind the C-ABI (gfx950).
+//
+// Host side of BaProcessor.__execute_bundle_adjustment (ba_processor.py:274-439) and of its caller, the
+// per-view loop of BaProcessor.process (ba_processor.py:137-267): create / destroy, state upload and
+// download, growing a resident scene in place (sfm_ba_append), the multi-GPU split, parity hooks.
+//
+// Everything that scales with the scene is built ON THE DEVICE: the host uploads the caller's CSR as it is
+// (one copy per array) and ba_structure_kernel validates it, derives obs_pt, the per-point 18-camera block
+// offsets of the sparse Schur product and the longest track; sfm_ba_append uploads only the NEW cameras,
+// points and observations and merges them into the (point, camera)-sorted list with a count / scan /
+// bucket / merge kernel chain.  The host never loops over observations.
+#include <algorithm>
+#include <vector>
+
+#include "sfm_ba.h"
+
+namespace sfm {
+
+// ---------------------------------------------------------------------------------------------
+// Structure check + derived index arrays, one thread per point.
+// sinfo[0] = first failure code (1 pt_ptr not monotone, 2 camera out of range, 3 cameras of a track not strictly
+// increasing), sinfo[1] = its index (point, observation, point), sinfo[2] = longest track.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void structure_fail(int* sinfo, int code, int index) {
+  if (atomicCAS(&sinfo[0], 0, code) == 0) sinfo[1] = index;
+}
+
+__global__ void ba_structure_kernel(int V, int N, long long M, const int* __restrict__ pt_ptr,
+                                    const int* __restrict__ cam_idx, int* __restrict__ obs_pt,
+                                    int* __restrict__ blk_ptr, int nblk, int* __restrict__ sinfo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int beg = pt_ptr[p], end = pt_ptr[p + 1];
+  int* row = blk_ptr + (size_t)p * (nblk + 1);
+  if (beg < 0 || end < beg || end > M) {
+    structure_fail(sinfo, 1, p);
+    for (int b = 0; b <= nblk; ++b) row[b] = 0;
+    return;
+  }
+  int prev = -1, b = 0;
+  for (int o = beg; o < end; ++o) {
+    const int c = cam_idx[o];
+    if (c < 0 || c >= V) { structure_fail(sinfo, 2, o); continue; }
+    if (c <= prev) structure_fail(sinfo, 3, p);
+    prev = c;
+    obs_pt[o] = p;
+    while (b < nblk && c >= b * kSchurCB) row[b++] = o;      // first observation whose camera is >= 18 b
+  }
+  while (b <= nblk) row[b++] = end;
+  atomicMax(&sinfo[2], end - beg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sfm_ba_append on the device.  New observation k = (obs_cam[k], obs_pt[k], u_new[k], v_new[k]).
+//   count   per new observation: range check, cnt[point]++
+//   scan    one workgroup: new_ptr = exclusive scan of (old track length + cnt), nstart = exclusive scan of cnt
+//   bucket  per new observation: its slot in its point's bucket (order inside a bucket is fixed by the merge's sort)
+//   merge   per point: sort the bucket by camera, merge with the old (sorted) track -> cam2 / u2 / v2
+// Duplicates (a pair already present) survive the merge as equal neighbours and are caught by
+// ba_structure_kernel's strictly-increasing check.
+// ---------------------------------------------------------------------------------------------
+__global__ void ba_append_count_kernel(long long n, int V2, int N2, const int* __restrict__ obs_cam,
+                                       const int* __restrict__ obs_pt, int* __restrict__ cnt, int* __restrict__ sinfo) {
+  const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int c = obs_cam[k], q = obs_pt[k];
+  if (c < 0 || c >= V2 || q < 0 || q >= N2) { structure_fail(sinfo, 4, (int)k); return; }
+  atomicAdd(&cnt[q], 1);
+}
+
+// exclusive prefix sums of two integer sequences in one pass, one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void ba_append_scan_kernel(int N, int N2, const int* __restrict__ old_ptr,
+                                                              const int* __restrict__ cnt, int* __restrict__ new_ptr,
+                                                              int* __restrict__ nstart) {
+  __shared__ int wsum[2][16];
+  __shared__ int carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2) carry[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < N2; base += 1024) {
+    const int q = base + tid;
+    int a = 0, b = 0;
+    if (q < N2) {
+      b = cnt[q];
+      a = b + (q < N ? old_ptr[q + 1] - old_ptr[q] : 0);
+    }
+    int sa = a, sb = b;                              // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int ta = __shfl_up(sa, off, 64), tb = __shfl_up(sb, off, 64);
+      if (lane >= off) { sa += ta; sb += tb; }
+    }
+    if (lane == 63) { wsum[0][wave] = sa; wsum[1][wave] = sb; }
+    __syncthreads();
+    int oa = carry[0], ob = carry[1];
+    for (int w = 0; w < wave; ++w) { oa += wsum[0][w]; ob += wsum[1][w]; }
+    if (q < N2) { new_ptr[q] = oa + sa - a; nstart[q] = ob + sb - b; }
+    __syncthreads();
+    if (tid == 1023) { carry[0] = oa + sa; carry[1] = ob + sb; }
+    __syncthreads();
+  }
+  if (tid == 0) { new_ptr[N2] = carry[0]; nstart[N2] = carry[1]; }
+}
+
+__global__ void ba_append_bucket_kernel(long long n, const int* __restrict__ obs_pt, const int* __restrict__ nstart,
+                                        int* __restrict__ fill, int* __restrict__ norder) {
+  const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int q = obs_pt[k];
+  norder[nstart[q] + atomicAdd(&fill[q], 1)] = (int)k;
+}
+
+__global__ void ba_append_merge_kernel(int N, int N2, const int* __restrict__ old_ptr, const int* __restrict__ old_cam,
+                                       const double* __restrict__ old_u, const double* __restrict__ old_v,
+                                       const int* __restrict__ new_ptr, const int* __restrict__ nstart,
+                                       int* __restrict__ norder, const int* __restrict__ obs_cam,
+                                       const double* __restrict__ u_new, const double* __restrict__ v_new,
+                                       int* __restrict__ cam2, double* __restrict__ u2, double* __restrict__ v2) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= N2) return;
+  const int nb = nstart[q], ne = nstart[q + 1];
+  for (int i = nb + 1; i < ne; ++i) {                 // insertion sort of the (short) bucket by camera
+    const int k = norder[i], c = obs_cam[k];
+    int j = i - 1;
+    while (j >= nb && obs_cam[norder[j]] > c) { norder[j + 1] = norder[j]; --j; }
+    norder[j + 1] = k;
+  }
+  int o = q < N ? old_ptr[q] : 0;
+  const int oe = q < N ? old_ptr[q + 1] : 0;
+  int i = nb, w = new_ptr[q];
+  while (o < oe || i < ne) {
+    const int co = o < oe ? old_cam[o] : 0x7fffffff;
+    const int cn = i < ne ? obs_cam[norder[i]] : 0x7fffffff;
+    if (co <= cn) { cam2[w] = co; u2[w] = old_u[o]; v2[w] = old_v[o]; ++o; }
+    else { const int k = norder[i]; cam2[w] = cn; u2[w] = u_new[k]; v2[w] = v_new[k]; ++i; }
+    ++w;
+  }
+}
+
+static int check_problem(const sfm_ba_problem* p) {
+  if (p == nullptr || p->magic != kBaMagic) {
+    set_error("invalid bundle-adjustment problem handle");
+    return SFM_E_HANDLE;
+  }
+  return SFM_OK;
+}
+
+static const char* status_name(int st) {
+  switch (st) {
+    case SFM_E_BAD_ROTATION: return "invalid rotation matrix";
+    case SFM_E_QW_ZERO: return "quaternion qw ~ 0";
+    case SFM_E_SQRT_DOMAIN: return "1 + trace(R) < 0";
+    default: return "unknown";
+  }
+}
+
+// Enqueue the structure kernel (all index arrays of p->dev must be on the device already).
+int ba_enqueue_structure(sfm_ba_problem* p) {
+  const BaDev& d = p->dev;
+  hipStream_t s = p->stream;
+  SFM_HIP(hipMemsetAsync(d.sinfo, 0, 4 * sizeof(int), s));
+  if (d.N > 0) {
+    const int nblk = (d.V + kSchurCB - 1) / kSchurCB;
+    ba_structure_kernel<<<(d.N + 255) / 256, 256, 0, s>>>(d.V, d.N, d.M, d.pt_ptr, d.cam_idx, d.obs_pt, p->schur_blk_ptr, nblk, d.sinfo);
+    SFM_HIP(hipGetLastError());
+  }
+  return SFM_OK;
+}
+
+// Wait for the structure kernel and turn its verdict into a status / message.  `who` names the entry point.
+static int ba_finish_structure(sfm_ba_problem* p, const char* who) {
+  int info[4] = {0, 0, 0, 0};
+  SFM_HIP(hipMemcpyAsync(info, p->dev.sinfo, sizeof(info), hipMemcpyDeviceToHost, p->stream));
+  SFM_TRY(stream_sync(p->stream));
+  p->max_track = info[2];
+  switch (info[0]) {
+    case 0: return SFM_OK;
+    case 1: set_error("%s: pt_ptr not monotone at point %d", who, info[1]); break;
+    case 2: set_error("%s: cam_idx[%d] out of range", who, info[1]); break;
+    case 3: set_error("%s: observations of point %d are not sorted by strictly increasing camera "
+                      "(a camera observes the point twice, or the point is already observed by it)", who, info[1]); break;
+    default: set_error("%s: observation %d (camera, point) out of range", who, info[1]); break;
+  }
+  return SFM_E_SHAPE;
+}
+
+// Allocate a problem of the given sizes on `stream` (nothing uploaded, no structure yet).
+static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_ba_problem** out) {
+  sfm_ba_problem* p = new sfm_ba_problem();
+  p->stream = stream;
+  BaDev& d = p->dev;
+  d.V = V; d.N = N; d.M = M; d.P = 7 * V;
+  d.ld = ((d.P + 63) / 64) * 64;
+  auto fail = [&](int st) { sfm_ba_destroy(p); return st; };
+#define BA_ALLOC(ptr, count) do { hipError_t e_ = pool_alloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
+    if (e_ != hipSuccess) return fail(hip_fail(e_, "hipMalloc " #ptr, __LINE__)); } while (0)
+  BA_ALLOC(d.pt_ptr, (size_t)N + 1);
+  BA_ALLOC(d.cam_idx, (size_t)M);
+  BA_ALLOC(d.obs_pt, (size_t)M);
+  BA_ALLOC(d.u, (size_t)M);
+  BA_ALLOC(d.v, (size_t)M);
+  BA_ALLOC(d.cams, (size_t)V * 7);
+  BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
+  BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
+  BA_ALLOC(d.lin_ws, (sizeof(double) * V * 35 <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
+  BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
+  BA_ALLOC(d.delta, (size_t)d.ld);
+  BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
+  BA_ALLOC(d.status, 2);
+  BA_ALLOC(d.sinfo, 4);
+#undef BA_ALLOC
+  d.red = p->own_red;
+  if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, stream) != hipSuccess) return fail(SFM_E_HIP);
+  { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
+  *out = p;
+  return SFM_OK;
+}
+
+static int ba_upload(sfm_ba_problem* p, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return SFM_OK;
+  SFM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+  p->upload_bytes += (long long)bytes;
+  return SFM_OK;
+}
+
+}  // namespace sfm
+
+using namespace sfm;
+
+extern "C" {
+
+int sfm_ba_create(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                  sfm_ba_problem** out) {
+  SFM_TRY(ensure_init());
+  if (out == nullptr) { set_error("sfm_ba_create: out is null"); return SFM_E_SHAPE; }
+  *out = nullptr;
+  if (V < 1 || N < 0 || M < 0 || M > 0x7fffffffLL) {
+    set_error("sfm_ba_create: bad sizes V=%d N=%d M=%lld", V, N, (long long)M);
+    return SFM_E_SHAPE;
+  }
+  if (N == 0 && M > 0) { set_error("sfm_ba_create: %lld observations but no point", (long long)M); return SFM_E_SHAPE; }
+  if (M > 0 && uv_norm == nullptr) { set_error("sfm_ba_create: uv_norm is null"); return SFM_E_SHAPE; }
+  if (N > 0 && (pt_ptr[0] != 0 || pt_ptr[N] != M)) { set_error("sfm_ba_create: pt_ptr must span [0, M]"); return SFM_E_SHAPE; }
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(ba_alloc_problem(V, N, M, ctx().stream, &p));
+  BaDev& d = p->dev;
+  const int zero_ptr = 0;
+  int st = N > 0 ? ba_upload(p, d.pt_ptr, pt_ptr, sizeof(int) * ((size_t)N + 1)) : ba_upload(p, d.pt_ptr, &zero_ptr, sizeof(int));
+  if (st == SFM_OK) st = ba_upload(p, d.cam_idx, cam_idx, sizeof(int) * (size_t)M);
+  if (st == SFM_OK) st = ba_upload(p, d.u, uv_norm, sizeof(double) * (size_t)M);
+  if (st == SFM_OK) st = ba_upload(p, d.v, uv_norm + M, sizeof(double) * (size_t)M);
+  if (st == SFM_OK) st = ba_enqueue_structure(p);
+  if (st == SFM_OK) st = ba_finish_structure(p, "sfm_ba_create");      // synchronises: the caller's arrays are free again
+  if (st != SFM_OK) { (void)hipStreamSynchronize(p->stream); sfm_ba_destroy(p); return st; }
+  *out = p;
+  return SFM_OK;
+}
+
+int sfm_ba_destroy(sfm_ba_problem* p) {
+  if (p == nullptr) return SFM_OK;
+  if (p->magic != kBaMagic) { set_error("sfm_ba_destroy: invalid handle"); return SFM_E_HANDLE; }
+  if (ctx().inited && p->stream) (void)hipStreamSynchronize(p->stream);
+  BaDev& d = p->dev;
+  void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, p->schur_ws, p->schur_blk_ptr};
+  for (void* q : ptrs) if (q) pool_free(q);
+  for (auto& t : p->timers)
+    for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  p->magic = 0;
+  delete p;
+  return SFM_OK;
+}
+
+int sfm_ba_set_stream(sfm_ba_problem* p, void* hip_stream) {
+  SFM_TRY(check_problem(p));
+  SFM_HIP(hipStreamSynchronize(p->stream));
+  p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx().own;
+  return SFM_OK;
+}
+
+int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
+  SFM_TRY(check_problem(p));
+  switch (option) {
+    case SFM_OPT_SCHUR:
+      if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
+      p->schur_mode = value;
+      return SFM_OK;
+    case SFM_OPT_DEBUG:
+      p->debug = value;
+      if ((value & 8) && p->dev.stamps == nullptr) {
+        SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
+        SFM_HIP(hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 1024));
+      }
+      return SFM_OK;
+    case SFM_OPT_TIMING:
+      p->timing = value;   // bit k set = time kernel class k
+      return SFM_OK;
+    default:
+      set_error("unknown option %d", option);
+      return SFM_E_SHAPE;
+  }
+}
+
+int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
+  SFM_TRY(check_problem(p));
+  if (value == nullptr) { set_error("sfm_ba_info: value is null"); return SFM_E_SHAPE; }
+  switch (what) {
+    case SFM_INFO_SCHUR_KERNEL: *value = ba_schur_uses_mfma(p) ? SFM_SCHUR_MFMA : SFM_SCHUR_PAIRS; return SFM_OK;
+    case SFM_INFO_UPLOAD_BYTES: *value = p->upload_bytes; return SFM_OK;
+    case SFM_INFO_N_CAMS: *value = p->dev.V; return SFM_OK;
+    case SFM_INFO_N_PTS: *value = p->dev.N; return SFM_OK;
+    case SFM_INFO_N_OBS: *value = p->dev.M; return SFM_OK;
+    case SFM_INFO_MAX_TRACK: *value = p->max_track; return SFM_OK;
+    default: set_error("sfm_ba_info: unknown item %d", what); return SFM_E_SHAPE;
+  }
+}
+
+int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams) {
+  SFM_TRY(check_problem(p));
+  BaDev& d = p->dev;
+  SFM_TRY(ba_upload(p, d.cams, cams, sizeof(double) * 7 * d.V));
+  SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), p->stream));
+  SFM_TRY(stream_sync(p->stream));
+  p->prep_valid = false;
+  return SFM_OK;
+}
+
+int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts) {
+  SFM_TRY(check_problem(p));
+  BaDev& d = p->dev;
+  if (first < 0 || count < 0 || first + (long long)count > d.N) {
+    set_error("sfm_ba_set_points: range [%d, %d) outside the %d points", first, first + count, d.N);
+    return SFM_E_SHAPE;
+  }
+  SFM_TRY(ba_upload(p, d.px + first, pts, sizeof(double) * count));
+  SFM_TRY(ba_upload(p, d.py + first, pts + count, sizeof(double) * count));
+  SFM_TRY(ba_upload(p, d.pz + first, pts + 2 * (size_t)count, sizeof(double) * count));
+  SFM_TRY(stream_sync(p->stream));
+  return SFM_OK;
+}
+
+int sfm_ba_set_state(sfm_ba_problem* p, const double* cams, const double* pts) {
+  SFM_TRY(check_problem(p));
+  BaDev& d = p->dev;
+  SFM_TRY(ba_upload(p, d.cams, cams, sizeof(double) * 7 * d.V));
+  if (d.N > 0) {
+    SFM_TRY(ba_upload(p, d.px, pts, sizeof(double) * d.N));
+    SFM_TRY(ba_upload(p, d.py, pts + d.N, sizeof(double) * d.N));
+    SFM_TRY(ba_upload(p, d.pz, pts + 2 * (size_t)d.N, sizeof(double) * d.N));
+  }
+  SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), p->stream));
+  SFM_TRY(stream_sync(p->stream));
+  p->prep_valid = false;
+  return SFM_OK;
+}
+
+int sfm_ba_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+  SFM_TRY(check_problem(p));
+  return ba_enqueue_linearize_reduce(p, lambda, quirks);
+}
+
+int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
+  SFM_TRY(check_problem(p));
+  return ba_enqueue_solve_update(p, lambda, quirks);
+}
+
+int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks) {
+  SFM_TRY(check_problem(p));
+  if (iters < 0) { set_error("sfm_ba_iterate: iters < 0"); return SFM_E_SHAPE; }
+  for (int it = 0; it < iters; ++it) {
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
+  }
+  return SFM_OK;
+}
+
+int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
+  SFM_TRY(check_problem(p));
+  hipStream_t s = p->stream;
+  BaDev& d = p->dev;
+  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));     // validates the cameras even with zero iterations (ba:412)
+  int st[2] = {0, 0};
+  SFM_HIP(hipMemcpyAsync(cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToHost, s));
+  if (d.N > 0) {
+    SFM_HIP(hipMemcpyAsync(pts, d.px, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipMemcpyAsync(pts + d.N, d.py, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipMemcpyAsync(pts + 2 * (size_t)d.N, d.pz, sizeof(double) * d.N, hipMemcpyDeviceToHost, s));
+  }
+  SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
+  SFM_TRY(stream_sync(s));
+  if (st[0] != SFM_OK) {
+    set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]);
+    return st[0];
+  }
+  return SFM_OK;
+}
+
+int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int n_new_pts, const double* pts_new,
+                  int64_t n_new_obs, const int* obs_cam, const int* obs_pt, const double* uv_norm) {
+  SFM_TRY(check_problem(p));
+  if (n_new_cams < 0 || n_new_pts < 0 || n_new_obs < 0) { set_error("sfm_ba_append: negative count"); return SFM_E_SHAPE; }
+  BaDev& d = p->dev;
+  const int V2 = d.V + n_new_cams, N2 = d.N + n_new_pts;
+  const long long M2 = d.M + n_new_obs;
+  if (M2 > 0x7fffffffLL) { set_error("sfm_ba_append: too many observations"); return SFM_E_SHAPE; }
+  if (N2 == 0 && M2 > 0) { set_error("sfm_ba_append: observations but no point"); return SFM_E_SHAPE; }
+  hipStream_t s = p->stream;
+  sfm_ba_problem* q = nullptr;
+  SFM_TRY(ba_alloc_problem(V2, N2, M2, s, &q));
+  BaDev& e = q->dev;
+  auto run = [&]() -> int {
+    // only the NEW data crosses PCIe; it is accounted to the surviving handle
+    DevBuf<int> dcam, dpt, cnt, nstart, fill, norder;
+    DevBuf<double> duv;
+    const size_t n = (size_t)n_new_obs;
+    SFM_TRY(dcam.upload(obs_cam, n, s)); SFM_TRY(dpt.upload(obs_pt, n, s)); SFM_TRY(duv.upload(uv_norm, 2 * n, s));
+    p->upload_bytes += (long long)(n * (2 * sizeof(int) + 2 * sizeof(double)));
+    SFM_TRY(cnt.alloc((size_t)N2 + 1, s)); SFM_TRY(nstart.alloc((size_t)N2 + 1, s));
+    SFM_TRY(fill.alloc((size_t)N2 + 1, s)); SFM_TRY(norder.alloc(n, s));
+    SFM_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)N2 + 1), s));
+    SFM_HIP(hipMemsetAsync(fill.p, 0, sizeof(int) * ((size_t)N2 + 1), s));
+    SFM_HIP(hipMemsetAsync(e.sinfo, 0, 4 * sizeof(int), s));
+    if (n > 0) ba_append_count_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)n, V2, N2, dcam.p, dpt.p, cnt.p, e.sinfo);
+    {   // a bad (camera, point) index must stop the chain before the bucket kernel writes through it
+      int info[4] = {0, 0, 0, 0};
+      SFM_HIP(hipMemcpyAsync(info, e.sinfo, sizeof(info), hipMemcpyDeviceToHost, s));
+      SFM_TRY(stream_sync(s));
+      if (info[0] != 0) {
+        set_error("sfm_ba_append: observation %d = (camera %d, point %d) out of range", info[1], obs_cam[info[1]], obs_pt[info[1]]);
+        return SFM_E_SHAPE;
+      }
+    }
+    ba_append_scan_kernel<<<1, 1024, 0, s>>>(d.N, N2, d.pt_ptr, cnt.p, e.pt_ptr, nstart.p);
+    if (n > 0) ba_append_bucket_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)n, dpt.p, nstart.p, fill.p, norder.p);
+    if (N2 > 0) ba_append_merge_kernel<<<(N2 + 255) / 256, 256, 0, s>>>(d.N, N2, d.pt_ptr, d.cam_idx, d.u, d.v, e.pt_ptr, nstart.p, norder.p,
+                                                                        dcam.p, duv.p, duv.p + n, e.cam_idx, e.u, e.v);
+    SFM_HIP(hipGetLastError());
+    // state: old cameras / points stay on the device, the new ones are uploaded behind them
+    SFM_HIP(hipMemcpyAsync(e.cams, d.cams, sizeof(double) * 7 * d.V, hipMemcpyDeviceToDevice, s));
+    SFM_TRY(ba_upload(p, e.cams + 7 * (size_t)d.V, cams_new, sizeof(double) * 7 * n_new_cams));
+    double* dst[3] = {e.px, e.py, e.pz};
+    const double* old[3] = {d.px, d.py, d.pz};
+    for (int k = 0; k < 3; ++k) {
+      if (d.N > 0) SFM_HIP(hipMemcpyAsync(dst[k], old[k], sizeof(double) * d.N, hipMemcpyDeviceToDevice, s));
+      SFM_TRY(ba_upload(p, dst[k] + d.N, pts_new + (size_t)k * n_new_pts, sizeof(double) * n_new_pts));
+    }
+    SFM_TRY(ba_enqueue_structure(q));
+    return ba_finish_structure(q, "sfm_ba_append");
+  };
+  const int st = run();
+  if (st != SFM_OK) { (void)hipStreamSynchronize(s); sfm_ba_destroy(q); return st; }
+  // the handle keeps its identity, options, stream and counters; the old buffers leave with q
+  q->schur_mode = p->schur_mode; q->debug = p->debug; q->timing = p->timing; q->quirks = p->quirks;
+  const bool had_external_red = p->dev.red != p->own_red;
+  std::swap(p->dev, q->dev);
+  std::swap(p->own_red, q->own_red);
+  std::swap(p->schur_ws, q->schur_ws);
+  std::swap(p->schur_blk_ptr, q->schur_blk_ptr);
+  std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
+  std::swap(p->max_track, q->max_track);
+  // an externally bound reduced buffer has the wrong size when cameras were added: the library's own buffer takes
+  // over and the caller binds a new one (sfm_ba_reduced_buffer reports the new size); with the camera count
+  // unchanged the binding survives
+  if (had_external_red && n_new_cams == 0) p->dev.red = q->dev.red;
+  else p->dev.red = p->own_red;
+  q->dev.red = q->own_red;
+  p->cur = 0; p->prep_valid = false; p->red_clean = false; p->lin_rows = 0;
+  std::swap(p->dev.stamps, q->dev.stamps);      // the diagnostic stamp buffer stays with the handle
+  return sfm_ba_destroy(q);
+}
+
+int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {
+  SFM_TRY(check_problem(p));
+  if (device_ptr) *device_ptr = p->dev.red;
+  if (n_doubles) *n_doubles = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  if (ld) *ld = p->dev.ld;
+  return SFM_OK;
+}
+
+int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
+  SFM_TRY(check_problem(p));
+  const int64_t need = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  p->red_clean = false;
+  if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
+  if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }
+  p->dev.red = static_cast<double*>(device_ptr);
+  return SFM_OK;
+}
+
+int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches) {
+  SFM_TRY(check_problem(p));
+  if (kernel_id < 0 || kernel_id >= SFM_K_COUNT) { set_error("bad kernel id %d", kernel_id); return SFM_E_SHAPE; }
+  SFM_HIP(hipStreamSynchronize(p->stream));
+  KernelTimer& t = p->timers[kernel_id];
+  double tot = 0;
+  for (int i = 0; i < t.used; ++i) {
+    float ms = 0;
+    SFM_HIP(hipEventElapsedTime(&ms, t.ev[i].first, t.ev[i].second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = t.used;
+  return SFM_OK;
+}
+
+int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n) {
+  SFM_TRY(check_problem(p));
+  if (p->dev.stamps == nullptr || n < 0 || n > 1024) { set_error("debug stamps not enabled (SFM_OPT_DEBUG bit 8)"); return SFM_E_SHAPE; }
+  SFM_HIP(hipStreamSynchronize(p->stream));
+  SFM_HIP(hipMemcpy(out, p->dev.stamps, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+  return SFM_OK;
+}
+
+int sfm_ba_reset_timing(sfm_ba_problem* p) {
+  SFM_TRY(check_problem(p));
+  SFM_HIP(hipStreamSynchronize(p->stream));
+  for (auto& t : p->timers) t.used = 0;
+  return SFM_OK;
+}
+
+int sfm_ba_solve(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm, double* cams,
+                 double* pts, double lambda, int iters, int quirks) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  int st = sfm_ba_set_state(p, cams, pts);
+  if (st == SFM_OK) st = sfm_ba_iterate(p, lambda, iters, quirks);
+  if (st == SFM_OK) st = sfm_ba_get_state(p, cams, pts);
+  sfm_ba_destroy(p);
+  return st;
+}
+
+int sfm_ba_residual_jacobian(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                             const double* cams, const double* pts, int quirks, double* r, double* Jp, double* Jx) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  auto run = [&]() -> int {
+    SFM_TRY(sfm_ba_set_state(p, cams, pts));
+    SFM_TRY(ba_enqueue_prep(p));
+    if (M == 0) return SFM_OK;
+    hipStream_t s = p->stream;
+    DevBuf<double> dr, djp, djx;
+    SFM_TRY(dr.alloc(2 * (size_t)M, s)); SFM_TRY(djp.alloc(14 * (size_t)M, s)); SFM_TRY(djx.alloc(6 * (size_t)M, s));
+    ba_enqueue_residual_jacobian(p, quirks, dr.p, djp.p, djx.p);
+    SFM_HIP(hipGetLastError());
+    SFM_TRY(dr.download(r, 2 * (size_t)M, s)); SFM_TRY(djp.download(Jp, 14 * (size_t)M, s)); SFM_TRY(djx.download(Jx, 6 * (size_t)M, s));
+    int st[2] = {0, 0};
+    SFM_HIP(hipMemcpyAsync(st, p->dev.status, sizeof(st), hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
+    return SFM_OK;
+  };
+  const int st = run();
+  sfm_ba_destroy(p);
+  return st;
+}
+
+int sfm_ba_reduced_system(int V, int N, int64_t M, const int* pt_ptr, const int* cam_idx, const double* uv_norm,
+                          const double* cams, const double* pts, double lambda, int quirks, int schur_mode, double* S,
+                          double* rhs) {
+  sfm_ba_problem* p = nullptr;
+  SFM_TRY(sfm_ba_create(V, N, M, pt_ptr, cam_idx, uv_norm, &p));
+  auto run = [&]() -> int {
+    SFM_TRY(sfm_ba_set_option(p, SFM_OPT_SCHUR, schur_mode));
+    SFM_TRY(sfm_ba_set_state(p, cams, pts));
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    hipStream_t s = p->stream;
+    const BaDev& d = p->dev;
+    DevBuf<double> dS, drhs;
+    SFM_TRY(dS.alloc((size_t)d.P * d.P, s)); SFM_TRY(drhs.alloc((size_t)d.P, s));
+    ba_enqueue_symmetrize(p, lambda, dS.p, drhs.p);
+    SFM_HIP(hipGetLastError());
+    SFM_TRY(dS.download(S, (size_t)d.P * d.P, s));
+    SFM_TRY(drhs.download(rhs, (size_t)d.P, s));
+    int st[2] = {0, 0};
+    SFM_HIP(hipMemcpyAsync(st, d.status, sizeof(st), hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    if (st[0] != SFM_OK) { set_error("bundle adjustment: %s for camera %d", status_name(st[0]), st[1]); return st[0]; }
+    return SFM_OK;
+  };
+  const int st = run();
+  sfm_ba_destroy(p);
+  return st;
+}
+
+}  // extern "C"

@@ -553,20 +553,9 @@ int ba_schur_plan(sfm_ba_problem* p) {
   // tens of gigabytes for scenes that will never take it
   p->schur_mfma_ok = d.N > 0 && ws_dense + zd_bytes <= ((size_t)32 << 30);
   SFM_HIP(pool_alloc(&p->schur_ws, std::max(p->schur_mfma_ok ? ws_dense : 0, ws_pairs)));
-  // per-point block offsets: blk_ptr[p][b] = first observation of point p whose camera is >= 18 b
-  const int nb1 = pp.nblk + 1;
-  std::vector<int> bp((size_t)std::max(1, d.N) * nb1, 0);
-  for (int q = 0; q < d.N; ++q) {
-    int o = p->h_pt_ptr[q];
-    const int oe = p->h_pt_ptr[q + 1];
-    for (int b = 0; b < nb1; ++b) {
-      while (o < oe && p->h_cam_idx[o] < b * CB) ++o;
-      bp[(size_t)q * nb1 + b] = o;
-    }
-    bp[(size_t)q * nb1 + pp.nblk] = oe;
-  }
-  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_blk_ptr), sizeof(int) * bp.size()));
-  SFM_HIP(hipMemcpy(p->schur_blk_ptr, bp.data(), sizeof(int) * bp.size(), hipMemcpyHostToDevice));
+  // per-point block offsets blk_ptr[p][b] = first observation of point p whose camera is >= 18 b (b = nblk: the
+  // end of the track); filled on the device by ba_structure_kernel
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_blk_ptr), sizeof(int) * (size_t)std::max(1, d.N) * (pp.nblk + 1)));
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),

@@ -16,8 +16,8 @@ namespace sfm {
 struct Context {
   bool inited = false;
   int device = -1;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
+  hipStream_t stream = nullptr;       // default stream of the library: `own` or the one installed by sfm_set_stream
+  hipStream_t own = nullptr;          // created at sfm_init, lives until sfm_shutdown
   int num_cus = 256;
 };
 
@@ -45,21 +45,38 @@ int hip_fail(hipError_t e, const char* what, int line);
     if (_s != SFM_OK) return _s; \
   } while (0)
 
+// Temporary device buffers go back to the caching pool when their DevBuf dies.  An entry point that returns
+// early with an error may still have copies or kernels in flight on its stream that use them, and the next
+// pool_alloc of that size class would hand the block out again: every DevBuf allocation therefore marks the
+// calling thread "unsynchronised" on its stream, stream_sync() clears the mark (the normal end of an entry point),
+// and the first DevBuf that dies while the mark is set synchronises that stream before releasing its block.
+struct PendingWork { bool dirty = false; hipStream_t stream = nullptr; };
+PendingWork& pending_work();
+int stream_sync(hipStream_t s);
+
 // RAII device buffer for the host-pointer convenience entry points.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
-  ~DevBuf() { if (p) pool_free(p); }
-  int alloc(size_t count) {
+  ~DevBuf() {
+    if (!p) return;
+    PendingWork& w = pending_work();
+    if (w.dirty) { (void)hipStreamSynchronize(w.stream); w.dirty = false; }
+    pool_free(p);
+  }
+  int alloc(size_t count, hipStream_t s = nullptr) {
     n = count;
     if (count == 0) count = 1;
     hipError_t e = pool_alloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e != hipSuccess) return hip_fail(e, "hipMalloc", __LINE__);
+    PendingWork& w = pending_work();
+    w.dirty = true;
+    w.stream = s ? s : ctx().stream;
     return SFM_OK;
   }
   int upload(const T* host, size_t count, hipStream_t s) {
-    SFM_TRY(alloc(count));
+    SFM_TRY(alloc(count, s));
     if (count) SFM_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
     return SFM_OK;
   }

@@ -34,6 +34,18 @@ int hip_fail(hipError_t e, const char* what, int line) {
   return SFM_E_HIP;
 }
 
+PendingWork& pending_work() {
+  static thread_local PendingWork w;
+  return w;
+}
+
+int stream_sync(hipStream_t s) {
+  SFM_HIP(hipStreamSynchronize(s));
+  PendingWork& w = pending_work();
+  if (w.stream == s || w.stream == nullptr) w.dirty = false;
+  return SFM_OK;
+}
+
 int ensure_init() {
   if (ctx().inited) return SFM_OK;
   return sfm_init(0);
@@ -739,8 +751,8 @@ int sfm_init(int device) {
     return SFM_E_NO_DEVICE;
   }
   c.num_cus = prop.multiProcessorCount;
-  SFM_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  c.own_stream = true;
+  SFM_HIP(hipStreamCreateWithFlags(&c.own, hipStreamNonBlocking));
+  c.stream = c.own;
   c.device = device;
   c.inited = true;
   return SFM_OK;
@@ -750,8 +762,9 @@ int sfm_shutdown(void) {
   Context& c = ctx();
   if (!c.inited) return SFM_OK;
   (void)hipStreamSynchronize(c.stream);
+  if (c.stream != c.own) (void)hipStreamSynchronize(c.own);
   pool_release_all();
-  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+  if (c.own) (void)hipStreamDestroy(c.own);
   c = Context();
   return SFM_OK;
 }
@@ -759,21 +772,16 @@ int sfm_shutdown(void) {
 int sfm_set_stream(void* hip_stream) {
   SFM_TRY(ensure_init());
   Context& c = ctx();
+  // the library's own stream lives from sfm_init to sfm_shutdown, so a problem that captured it as its default
+  // (sfm_ba_create) never holds a dangling handle; an installed stream stays the caller's
   SFM_HIP(hipStreamSynchronize(c.stream));
-  if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
-  if (hip_stream == nullptr) {
-    SFM_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    c.own_stream = true;
-  } else {
-    c.stream = reinterpret_cast<hipStream_t>(hip_stream);
-    c.own_stream = false;
-  }
+  c.stream = hip_stream == nullptr ? c.own : reinterpret_cast<hipStream_t>(hip_stream);
   return SFM_OK;
 }
 
 int sfm_synchronize(void) {
   SFM_TRY(ensure_init());
-  SFM_HIP(hipStreamSynchronize(ctx().stream));
+  SFM_TRY(stream_sync(ctx().stream));
   return SFM_OK;
 }
 
@@ -787,7 +795,7 @@ int sfm_quat_to_rot(int n, const double* q, double* R, int* status) {
   quat_to_rot_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dq.p, dR.p, dst.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dR.download(R, 9 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -801,7 +809,7 @@ int sfm_rot_to_quat(int n, const double* R, double* q, int* status) {
   rot_to_quat_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dR.p, dq.p, dst.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dq.download(q, 4 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -816,7 +824,7 @@ int sfm_jac_cam(int n, const double* R, const double* C, const double* X, int qu
   jac_cam_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dR.p, dC.p, dX.p, quirks, dJ.p, dst.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dJ.download(Jp, 14 * (size_t)n, s)); SFM_TRY(dst.download(status, n, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -831,7 +839,7 @@ int sfm_jac_pt(int n, int n_views, const double* projs, const double* X, double*
   jac_pt_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, n_views, dP.p, dX.p, dJ.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dJ.download(Jx, 6 * (size_t)n * n_views, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -853,7 +861,7 @@ int sfm_tri_nonlinear(int m, int n_views, const double* projs, const double* uv,
   launch_tri_nonlinear(m, n_views, dP.p, dUV.p, dX.p, lambda, iters, dO.p, lds, s);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -870,7 +878,7 @@ int sfm_tri_linear(int m, int n_views, const double* projs, const double* uv, do
   tri_linear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, dP.p, dUV.p, dO.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -891,7 +899,7 @@ int sfm_triangulate(int m, int n_views, const double* projs, const double* uv, d
   launch_tri_nonlinear(m, n_views, dP.p, dUV.p, dL.p, lambda, iters, dO.p, lds, s);   // tri:86
   SFM_HIP(hipGetLastError());
   SFM_TRY(dO.download(X_out, 4 * (size_t)m, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -914,7 +922,7 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const do
   SFM_HIP(hipGetLastError());
   std::vector<int> counts(n_hyp);
   SFM_TRY(dCnt.download(counts.data(), n_hyp, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   // the reference keeps the FIRST hypothesis with a strictly larger count, starting from 0 inliers / identity
   // pose (campose:524-560)
   int best = -1, best_cnt = 0;
@@ -934,7 +942,7 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const do
   SFM_TRY(dMask.download(inlier_mask, n, s));
   SFM_HIP(hipMemcpyAsync(R_out, dR.p + 9 * (size_t)best, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
   SFM_HIP(hipMemcpyAsync(C_out, dC.p + 3 * (size_t)best, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -963,7 +971,7 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   SFM_HIP(hipGetLastError());
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 

@@ -256,7 +256,7 @@ int sfm_fundamental_eight_point(int n, const double* pairs, int n_hyp, const int
   fund_eight_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, dS.p, dP.p, dF.p, dSt.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dF.download(F_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dSt.download(status, n_hyp, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -284,7 +284,7 @@ int sfm_fundamental_ransac(int n, const double* left, const double* right, int n
   std::vector<int> st(n_hyp), counts(n_hyp, 8);
   SFM_TRY(dSt.download(st.data(), n_hyp, s));
   if (!exact) SFM_TRY(dCnt.download(counts.data(), n_hyp, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   for (int h = 0; h < n_hyp; ++h)
     if (st[h] != SFM_OK) { set_error("f__ rank is not equal to 2 (hypothesis %d)", h); return SFM_E_RANK; }
   // the reference keeps the FIRST hypothesis with a strictly larger count, starting from 0 inliers (epipolar:222-245)
@@ -303,7 +303,7 @@ int sfm_fundamental_ransac(int n, const double* left, const double* right, int n
   SFM_HIP(hipGetLastError());
   SFM_TRY(dMask.download(inlier_mask, n, s));
   SFM_TRY(dFp.download(F_out, 9, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -318,7 +318,7 @@ int sfm_essential_from_fundamental(const double F[9], const double K_left[9], co
   SFM_HIP(hipGetLastError());
   int st = SFM_OK;
   SFM_TRY(dE.download(E_out, 9, s)); SFM_TRY(dSt.download(&st, 1, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   if (st != SFM_OK) set_error("esse_mat rank is not equal to 2");
   return st;
 }
@@ -331,7 +331,7 @@ int sfm_pose_candidates(const double E[9], double R_out[18], double C1_out[3]) {
   pose_candidates_kernel<<<1, 64, 0, s>>>(dE.p, dR.p, dC.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dR.download(R_out, 18, s)); SFM_TRY(dC.download(C1_out, 3, s));
-  SFM_HIP(hipStreamSynchronize(s));
+  SFM_TRY(stream_sync(s));
   return SFM_OK;
 }
 
@@ -349,7 +349,7 @@ int sfm_cheirality(int k, int n, const double P1[12], const double* P2, const do
     cheirality_kernel<<<dim3((n + 255) / 256, k), 256, 0, s>>>(n, dP1.p, dP2.p, dX.p, dM.p, dC.p);
     SFM_HIP(hipGetLastError());
     SFM_TRY(dM.download(mask, (size_t)k * n, s)); SFM_TRY(dC.download(counts, k, s));
-    SFM_HIP(hipStreamSynchronize(s));
+    SFM_TRY(stream_sync(s));
   } else {
     for (int c = 0; c < k; ++c) counts[c] = 0;
   }

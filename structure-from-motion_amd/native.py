@@ -19,6 +19,7 @@ SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA = 0, 1, 2
 OPT_SCHUR, OPT_TIMING, OPT_DEBUG = 1, 2, 3
 K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
+INFO_SCHUR_KERNEL, INFO_UPLOAD_BYTES, INFO_N_CAMS, INFO_N_PTS, INFO_N_OBS, INFO_MAX_TRACK = 1, 2, 3, 4, 5, 6
 
 # every symbol include/sfm_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -29,6 +30,7 @@ EXPORTS = (
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
+    "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
@@ -73,6 +75,11 @@ def load():
         getattr(lib, name).argtypes = [ctypes.c_void_p]
     lib.sfm_ba_set_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.sfm_ba_set_state.argtypes = [ctypes.c_void_p, _dp, _dp]
+    lib.sfm_ba_set_stream.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.sfm_ba_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.sfm_ba_set_cameras.argtypes = [ctypes.c_void_p, _dp]
+    lib.sfm_ba_set_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _dp]
+    lib.sfm_ba_append.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64, _ip, _ip, _dp]
     lib.sfm_ba_get_state.argtypes = [ctypes.c_void_p, _dp, _dp]
     lib.sfm_ba_iterate.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int]
     lib.sfm_ba_linearize_reduce.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
@@ -369,11 +376,34 @@ class BaProblem:
     def set_option(self, option, value):
         check(self._lib.sfm_ba_set_option(self._h, option, value))
 
+    def set_stream(self, stream_ptr):
+        """Run this problem on an existing HIP stream (``torch.cuda.Stream.cuda_stream``); 0 / None = the library's own."""
+        check(self._lib.sfm_ba_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def info(self, what):
+        v = ctypes.c_int64()
+        check(self._lib.sfm_ba_info(self._h, int(what), ctypes.byref(v)))
+        return int(v.value)
+
+    @property
+    def upload_bytes(self):
+        return self.info(INFO_UPLOAD_BYTES)
+
     def set_state(self, cams, pts):
         cams = f64(cams).reshape(-1, 7); pts = f64(pts)
         if cams.shape[0] != self.n_cams or pts.shape != (3, self.n_pts):
             raise ValueError("state shapes do not match the problem")
         check(self._lib.sfm_ba_set_state(self._h, dptr(cams), dptr(pts)))
+
+    def set_cameras(self, cams):
+        cams = f64(cams).reshape(-1, 7)
+        if cams.shape[0] != self.n_cams:
+            raise ValueError("camera count does not match the problem")
+        check(self._lib.sfm_ba_set_cameras(self._h, dptr(cams)))
+
+    def set_points(self, first, pts):
+        pts = f64(pts).reshape(3, -1)
+        check(self._lib.sfm_ba_set_points(self._h, int(first), pts.shape[1], dptr(pts)))
 
     def iterate(self, lam, iters, quirks=QUIRKS_REFERENCE):
         check(self._lib.sfm_ba_iterate(self._h, float(lam), int(iters), int(quirks)))
@@ -397,8 +427,6 @@ class BaProblem:
         obs_cam = i32(obs_cam).ravel(); obs_pt = i32(obs_pt).ravel(); uv_norm = f64(uv_norm).reshape(2, -1)
         if not (obs_cam.shape[0] == obs_pt.shape[0] == uv_norm.shape[1]):
             raise ValueError("append: obs_cam, obs_pt and uv_norm disagree in length")
-        self._lib.sfm_ba_append.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, ctypes.c_int, _dp, ctypes.c_int64,
-                                            _ip, _ip, _dp]
         check(self._lib.sfm_ba_append(self._h, cams_new.shape[0], dptr(cams_new), pts_new.shape[1], dptr(pts_new),
                                       obs_cam.shape[0], iptr(obs_cam), iptr(obs_pt), dptr(uv_norm)))
         self.n_cams += cams_new.shape[0]

@@ -28,7 +28,7 @@ import math
 import numpy as np
 
 from . import native
-from .geometry import (pack_camera, quaternion_to_rotation, quaternion_to_rotation_unchecked)
+from .geometry import (pack_cameras, quaternion_to_rotation_unchecked, quaternions_to_rotations)
 from .observations import build_observations, gather_normalised_keys
 
 
@@ -267,39 +267,147 @@ class HipCamposeProcessor(HipCamposeMixin):
 
 
 # ------------------------------------------------------------------------------------------------
+_CODE_SHIFT = 1 << 20        # observation code = point * 2^20 + view (the reference caps views at filter_size = 10)
+
+
+class _ResidentScene:
+    """What the drop-in keeps between two BA calls of one processor: the device-resident problem and a host
+    picture of what it holds (self-rows of the track tables, observation codes and key indices, intrinsics,
+    the points of the last write-back), enough to decide what is NEW in the next call."""
+
+    def __init__(self):
+        self.prob = None
+        self.rows = []            # copies of track_list[v].table[v, :]
+        self.ks = []              # copies of view.k
+        self.n_pts = 0
+        self.code = np.empty(0, dtype=np.int64)       # sorted (point, view) codes of the resident observations
+        self.key_idx = np.empty(0, dtype=np.int32)
+        self.pts_written = None   # (3, N) the points of the last write-back
+        self.retired_bytes = 0    # upload bytes of problems this scene has replaced
+
+    def close(self):
+        if self.prob is not None:
+            self.retired_bytes += self.prob.upload_bytes
+            self.prob.close()
+            self.prob = None
+
+    @property
+    def upload_bytes(self):
+        return self.retired_bytes + (self.prob.upload_bytes if self.prob is not None else 0)
+
+
 class HipBaMixin:
     """``BaProcessor.__execute_bundle_adjustment`` (ba_processor.py:274-439) on the device.
 
     Reads ``self.view_processor.view_list`` (``.rot/.loc/.k/.key_pts[i].pt``),
     ``self.key_tracker.track_list[i].table``, ``self.tri_processor.tri_pts``, ``self.iteration``,
     ``self.damping_factor``; writes the refined poses back through ``view.update_cam_pose`` and the
-    refined points into ``tri_pts[0:3, :]`` in place; prints the reference's DEBUG lines."""
+    refined points into ``tri_pts[0:3, :]`` in place; prints the reference's DEBUG lines.
+
+    The reference runs this after EVERY registered view, over all views and all points
+    (ba_processor.py:267).  The scene therefore stays resident on the device between calls
+    (``ba_resident``): each call diffs the observation list against what the device holds and uploads
+    only what is new -- the new view's pose, the new points, the new observations (``sfm_ba_append``) --
+    plus the 7 V camera doubles (the reference re-derives q from R every call, ba:285-288) and whatever
+    old point the caller changed since the last write-back.  If anything was REMOVED (an observation,
+    a point, a view) or an existing key / intrinsic changed, the problem is rebuilt from scratch.
+    ``ba_upload_bytes`` reports the PCIe bytes spent so far; ``ba_release()`` frees the device copy."""
 
     ba_quirk_flags = native.QUIRKS_REFERENCE
     ba_verbose = True          # the reference prints unconditionally (ba:418-439)
+    ba_resident = True         # keep the problem on the device between calls (False: one sfm_ba_solve per call)
+    ba_last_action = None      # "create" | "append" | "reuse" | "solve": what the last call did (diagnostics / tests)
+
+    def ba_release(self):
+        scene = self.__dict__.pop("_hip_scene", None)
+        if scene is not None:
+            scene.close()
+
+    @property
+    def ba_upload_bytes(self):
+        scene = self.__dict__.get("_hip_scene")
+        return scene.upload_bytes if scene is not None else 0
+
+    # ---- resident problem ---------------------------------------------------------------------------
+    def _ba_sync_structure(self, views, tri_num, init_cam_poses, init_tri_pts):
+        """Bring the resident problem to the current observation list; returns it."""
+        scene = self.__dict__.get("_hip_scene")
+        if scene is None:
+            scene = self.__dict__["_hip_scene"] = _ResidentScene()
+        view_num = len(views)
+        rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
+        n_old = len(scene.rows)
+        same_intrinsics = scene.prob is not None and view_num >= n_old and all(
+            np.array_equal(views[v].k, scene.ks[v]) for v in range(n_old))
+        if (same_intrinsics and view_num == n_old and tri_num == scene.n_pts
+                and all(r.shape == c.shape and np.array_equal(r, c) for r, c in zip(rows, scene.rows))):
+            self.ba_last_action = "reuse"
+            return scene
+        pt_ptr, cam_idx, pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
+        code = pt_idx.astype(np.int64) * _CODE_SHIFT + cam_idx
+        grown = False
+        if same_intrinsics and tri_num >= scene.n_pts and code.shape[0] >= scene.code.shape[0] and view_num < _CODE_SHIFT:
+            pos = np.searchsorted(code, scene.code)
+            inside = pos < code.shape[0]
+            if np.all(inside) and np.array_equal(code[pos], scene.code) and np.array_equal(key_idx[pos], scene.key_idx):
+                fresh = np.ones(code.shape[0], dtype=bool)
+                fresh[pos] = False
+                sel = np.flatnonzero(fresh)
+                uv_new = gather_normalised_keys(views, cam_idx[sel], key_idx[sel])              # ba:339-342, new keys only
+                scene.prob.append(init_cam_poses[n_old:], init_tri_pts[:, scene.n_pts:tri_num], cam_idx[sel], pt_idx[sel], uv_new)
+                grown = True
+                self.ba_last_action = "append"
+        if not grown:
+            scene.close()
+            uv_norm = gather_normalised_keys(views, cam_idx, key_idx)
+            scene.prob = native.BaProblem(view_num, pt_ptr, cam_idx, uv_norm)
+            scene.pts_written = None
+            self.ba_last_action = "create"
+        scene.rows = [np.array(r, copy=True) for r in rows]
+        scene.ks = [np.array(v.k, dtype=np.float64, copy=True) for v in views]
+        scene.n_pts = tri_num
+        scene.code, scene.key_idx = code, key_idx
+        return scene
+
+    @staticmethod
+    def _ba_host_state(views, tri_pts):
+        cams = pack_cameras(np.stack([np.asarray(v.rot, dtype=np.float64) for v in views]),
+                            np.stack([np.asarray(v.loc, dtype=np.float64).reshape(3) for v in views]))   # ba:285-288
+        return cams, np.ascontiguousarray(tri_pts[0:3, :], dtype=np.float64)                               # ba:292-294
 
     def execute_bundle_adjustment(self):
         views = self.view_processor.view_list
         tri_pts = self.tri_processor.tri_pts
         view_num = len(views)
         tri_num = tri_pts.shape[1]
+        init_cam_poses, init_tri_pts = self._ba_host_state(views, tri_pts)
 
-        init_cam_poses = np.zeros((view_num, 7))
-        for view_idx in range(view_num):
-            init_cam_poses[view_idx] = pack_camera(views[view_idx].rot, views[view_idx].loc)   # ba:285-288
-        init_tri_pts = np.ascontiguousarray(tri_pts[0:3, :], dtype=np.float64)                 # ba:292-294
+        if self.ba_resident:
+            scene = self._ba_sync_structure(views, tri_num, init_cam_poses, init_tri_pts)
+            prob = scene.prob
+            prob.set_cameras(init_cam_poses)
+            done = 0 if scene.pts_written is None else min(scene.pts_written.shape[1], tri_num)
+            if self.ba_last_action == "create":
+                prob.set_points(0, init_tri_pts)
+            else:
+                # points the caller did not touch since the last write-back are already on the device (bit for
+                # bit what get_state returned); appended points went up with sfm_ba_append
+                if done and not np.array_equal(init_tri_pts[:, :done], scene.pts_written[:, :done]):
+                    prob.set_points(0, init_tri_pts[:, :done])
+            prob.iterate(self.damping_factor, self.iteration, self.ba_quirk_flags)
+            cams, pts = prob.get_state()
+            scene.pts_written = pts
+        else:
+            rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
+            pt_ptr, cam_idx, _pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
+            uv_norm = gather_normalised_keys(views, cam_idx, key_idx)                              # ba:339-342
+            cams, pts = native.ba_solve(view_num, pt_ptr, cam_idx, uv_norm, init_cam_poses, init_tri_pts,
+                                        self.damping_factor, self.iteration, self.ba_quirk_flags)
+            self.ba_last_action = "solve"
 
-        rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
-        pt_ptr, cam_idx, _pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
-        uv_norm = gather_normalised_keys(views, cam_idx, key_idx)                              # ba:339-342
-
-        cams, pts = native.ba_solve(view_num, pt_ptr, cam_idx, uv_norm, init_cam_poses, init_tri_pts,
-                                    self.damping_factor, self.iteration, self.ba_quirk_flags)
-
+        rots = quaternions_to_rotations(cams[:, 3:7])                                              # ba:412 (validated)
         for view_idx in range(view_num):                                                       # ba:409-413
-            loc = cams[view_idx, 0:3].reshape(3, 1).copy()
-            rot = quaternion_to_rotation(cams[view_idx, 3:7].reshape(4, 1))
-            views[view_idx].update_cam_pose(rot, loc)
+            views[view_idx].update_cam_pose(rots[view_idx], cams[view_idx, 0:3].reshape(3, 1).copy())
         tri_pts[0:3, :] = pts                                                                  # ba:415-416
 
         if self.ba_verbose:                                                                    # ba:418-439

@@ -53,14 +53,32 @@ class HipShardEngine:
         self.torch = torch
         self.device = torch.device(device)
         native.init(self.device.index or 0)
-        # a dedicated (non-null) torch stream: the library launches on it and the collective is issued
-        # under it, so RCCL's internal stream waits for the kernels and vice versa
+        # a dedicated (non-null) torch stream OF THIS ENGINE: its problem launches on it (sfm_ba_set_stream: the
+        # stream belongs to the problem, not to the library, so several engines in one process do not interfere)
+        # and the collective is issued under it, so RCCL's internal stream waits for the kernels and vice versa
         self.stream = torch.cuda.Stream(self.device)
-        native.set_stream(self.stream.cuda_stream)
         self.prob = native.BaProblem(n_cams, pt_ptr_local, cam_idx_local, uv_local)
+        self.prob.set_stream(self.stream.cuda_stream)
+        self._bind_reduced()
+
+    def _bind_reduced(self):
+        """(Re)allocate the all-reduce tensor for the problem's current camera count and bind it.  The tensor is
+        created under the engine's stream, so its zero-fill is ordered before the first kernel that uses it."""
+        torch = self.torch
         _ptr, n, self.ld = self.prob.reduced_buffer()
-        self.reduced = torch.zeros(n, dtype=torch.float64, device=self.device)
+        with torch.cuda.stream(self.stream):
+            self.reduced = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self.reduced.record_stream(self.stream)
         self.prob.bind_reduced_buffer(self.reduced.data_ptr(), n)
+
+    def append(self, cams_new, pts_new, obs_cam, obs_pt, uv_norm):
+        """Grow this rank's shard (new cameras go to EVERY rank, new points / observations to their owner).  The
+        reduced buffer follows the camera count: a new tensor is bound before the next linearisation, so the
+        all-reduce never runs on a stale one."""
+        n_before = self.prob.n_cams
+        self.prob.append(cams_new, pts_new, obs_cam, obs_pt, uv_norm)
+        if self.prob.n_cams != n_before:
+            self._bind_reduced()
 
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
@@ -81,7 +99,6 @@ class HipShardEngine:
     def close(self):
         self.prob.bind_reduced_buffer(0, 0)
         self.prob.close()
-        native.set_stream(0)
 
 
 class ShardedBa:

@@ -30,8 +30,13 @@ def test_append_equals_fresh_problem(hip, sfm, schur):
         # old points, old cameras seeing new points, new seeing new), in scrambled order
         new = np.flatnonzero(~keep)
         new = np.random.default_rng(3).permutation(new)
+        before = prob.upload_bytes
         prob.append(sc.cams_init[v0:], sc.pts_init[:, n0:], sc.cam_idx[new], sc.pt_idx[new], uvn[:, new])
         assert (prob.n_cams, prob.n_pts, prob.n_obs) == (sc.n_cams, sc.n_pts, sc.cam_idx.shape[0])
+        assert prob.info(hip.INFO_N_OBS) == sc.cam_idx.shape[0] and prob.info(hip.INFO_N_CAMS) == sc.n_cams
+        # only the NEW data crossed PCIe: 56 B per camera, 24 B per point, 24 B per observation (cam, pt, u, v)
+        assert prob.upload_bytes - before == 56 * (sc.n_cams - v0) + 24 * (sc.n_pts - n0) + 24 * new.shape[0]
+        assert prob.info(hip.INFO_MAX_TRACK) == int(np.max(np.diff(sc.pt_ptr)))
         cams_b, pts_b = prob.get_state()
         assert np.array_equal(cams_b[:v0], cams_a) and np.array_equal(cams_b[v0:], sc.cams_init[v0:])
         assert np.array_equal(pts_b[:, :n0], pts_a) and np.array_equal(pts_b[:, n0:], sc.pts_init[:, n0:])
@@ -59,6 +64,14 @@ def test_append_rejects_bad_input(hip, sfm):
             prob.append(np.zeros((0, 7)), np.zeros((3, 0)), [1], [5], np.zeros((2, 1)))
         with pytest.raises(ValueError, match="out of range"):
             prob.append(np.zeros((0, 7)), np.zeros((3, 0)), [3], [5], np.zeros((2, 1)))
+        with pytest.raises(ValueError, match="out of range"):
+            prob.append(np.zeros((0, 7)), np.zeros((3, 0)), [1], [40], np.zeros((2, 1)))
+        # the same new pair twice in one call
+        with pytest.raises(ValueError, match="already observed"):
+            prob.append(np.zeros((1, 7)), np.zeros((3, 0)), [3, 3], [5, 5], np.zeros((2, 2)))
+        # a failed append leaves the problem as it was
+        assert (prob.n_cams, prob.n_pts, prob.n_obs) == (sc.n_cams, sc.n_pts, sc.cam_idx.shape[0])
+        assert prob.info(hip.INFO_N_CAMS) == sc.n_cams
         # an empty append is a no-op that keeps the state
         prob.append(np.zeros((0, 7)), np.zeros((3, 0)), [], [], np.zeros((2, 0)))
         cams, pts = prob.get_state()
@@ -86,14 +99,21 @@ def test_two_rank_emulation_on_one_gpu_equals_single_problem(hip, sfm, shape):
             eng.prob.set_option(hip.OPT_SCHUR, mode)
             eng.set_state(sc.cams_init, pts_l)
             engines.append(eng); ranges.append(rng)
-        torch.cuda.synchronize()
-        with engines[-1].stream_context():            # the library launches on the stream of the engine created last
-            for _ in range(3):
-                bufs = [e.linearize_reduce(5.0) for e in engines]
-                total = bufs[0] + bufs[1]               # <- all_reduce(SUM)
-                for b in bufs:
-                    b.copy_(total)
-                for e in engines:
+        # each engine launches on ITS OWN stream (sfm_ba_set_stream); the hand-made "all-reduce" runs on torch's
+        # default stream, so the three streams are joined explicitly where RCCL would order them
+        assert engines[0].stream.cuda_stream != engines[1].stream.cuda_stream
+        for _ in range(3):
+            bufs = []
+            for e in engines:
+                with e.stream_context():
+                    bufs.append(e.linearize_reduce(5.0))
+            torch.cuda.synchronize()
+            total = bufs[0] + bufs[1]               # <- all_reduce(SUM)
+            for b in bufs:
+                b.copy_(total)
+            torch.cuda.synchronize()
+            for e in engines:
+                with e.stream_context():
                     e.solve_update(5.0)
         states = [e.get_state() for e in engines]
     finally:
@@ -154,3 +174,33 @@ def test_incremental_growth_matches_oracle(hip, sfm, oracle):
             assert np.max(np.abs(cams_g - cams_o)) < 1e-9 * max(1.0, np.max(np.abs(cams_o))), v
             assert np.max(np.abs(pts_g - pts_o)) < 1e-9 * np.max(np.abs(pts_o)), v
         assert prob.n_cams == sc.n_cams and prob.n_pts == int(np.sum(born <= sc.n_cams - 1))
+
+
+def test_sharded_engine_append_rebinds_reduced_buffer(hip, sfm, oracle):
+    """A sharded engine that grows by a camera: the all-reduce tensor must follow the new camera count (a stale
+    binding would all-reduce a tensor the kernels no longer write).  One rank, the collective replaced by a check
+    that the tensor the engine hands out IS the buffer the problem writes."""
+    import torch
+    sh = sfm.sharding
+    sc = sfm.scenes.make_scene(5, 300, 0.7, seed=41)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    keep = sc.cam_idx < 4
+    ptr0 = np.zeros(sc.n_pts + 1, dtype=np.int32); np.add.at(ptr0, sc.pt_idx[keep] + 1, 1); ptr0 = np.cumsum(ptr0).astype(np.int32)
+    eng = sh.HipShardEngine(4, ptr0, sc.cam_idx[keep], uvn[:, keep], torch.device("cuda", 0))
+    try:
+        eng.set_state(sc.cams_init[:4], sc.pts_init)
+        n4 = eng.reduced.numel()
+        new = np.flatnonzero(~keep)
+        eng.append(sc.cams_init[4:], np.zeros((3, 0)), sc.cam_idx[new], sc.pt_idx[new], uvn[:, new])
+        assert eng.reduced.numel() >= n4 and eng.prob.reduced_buffer()[0] == eng.reduced.data_ptr()
+        seen = []
+        ba = sh.ShardedBa(eng, all_reduce=lambda t: seen.append((t.data_ptr(), float(t.abs().sum()))), world_size=1)
+        ba.iterate(5.0, 2)
+        torch.cuda.synchronize()
+        assert len(seen) == 2 and all(ptr == eng.reduced.data_ptr() and mass > 0 for ptr, mass in seen)
+        cams, pts = eng.get_state()
+    finally:
+        eng.close()
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    assert np.max(np.abs(cams - ocams)) < 1e-9 * np.max(np.abs(ocams))
+    assert np.max(np.abs(pts - opts)) < 1e-9 * np.max(np.abs(opts))

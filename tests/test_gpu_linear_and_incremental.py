@@ -160,6 +160,7 @@ def test_incremental_sfm_loop(hip, sfm, oracle):
 
     add_view(0, rots[0].copy(), locs[0].copy())
     known = np.zeros(n_pts, dtype=bool)
+    actions, uploaded = [], [0]
     for c in range(1, n_views):
         # --- pose of the new view: nonlinear PnP on the known points, started from a perturbed pose
         if known.any():
@@ -199,6 +200,14 @@ def test_incremental_sfm_loop(hip, sfm, oracle):
         bp._BaProcessor__execute_bundle_adjustment()
         full[:, :idx.max() + 1] = tp.tri_pts
         tp.tri_pts = full
+        # the scene stays resident between the per-view BA calls (ba_processor.py:267): after the first call only
+        # what is NEW goes up -- one camera (56 B), 180 points (24 B each), the new observations (24 B each: camera,
+        # point, two doubles) -- plus the 7 V camera doubles the reference re-derives from R on every call
+        actions.append(bp.ba_last_action)
+        uploaded.append(bp.ba_upload_bytes)
+        if c > 1:
+            n_new_obs = (c + 1) * idx.size - c * (idx.size - new.size)
+            assert uploaded[-1] - uploaded[-2] == 56 * 1 + 24 * new.size + 24 * n_new_obs + 56 * (c + 1)
         nobs = (c + 1) * idx.size
         cam_idx = np.tile(np.arange(c + 1), idx.size).astype(np.int32)
         pt_idx = np.repeat(idx, c + 1).astype(np.int32)
@@ -208,6 +217,32 @@ def test_incremental_sfm_loop(hip, sfm, oracle):
         ocams, opts = oracle.ba_sparse(cams0, pts0[:, :idx.max() + 1], cam_idx, pt_idx, uvn, 5, 3)
         gcams = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in views])
         assert rel(gcams, ocams) < 1e-9 and rel(tp.tri_pts[0:3, idx], opts[:, idx]) < 1e-9
+    assert actions == ["create"] + ["append"] * (n_views - 2)
+    # a further call with nothing new re-uses the resident structure: cameras only (56 V bytes)
+    before = bp.ba_upload_bytes
+    bp._BaProcessor__execute_bundle_adjustment()
+    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 56 * n_views
+    # ... a caller-side edit of an old point is noticed and uploaded (24 B per resident point), ...
+    tp.tri_pts[0, 3] += 1e-3
+    before = bp.ba_upload_bytes
+    bp._BaProcessor__execute_bundle_adjustment()
+    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 56 * n_views + 24 * n_pts
+    # ... and a REMOVED observation forces a rebuild that still matches a from-scratch solve
+    kt.track_list[2].table[2, 5] = -1
+    snap_views = [(v.rot.copy(), v.loc.copy()) for v in vp.view_list]
+    snap_pts = tp.tri_pts.copy()
+    bp._BaProcessor__execute_bundle_adjustment()
+    assert bp.ba_last_action == "create"
+    got = (np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list]), tp.tri_pts[0:3].copy())
+    for v, (r, l) in zip(vp.view_list, snap_views):
+        v.update_cam_pose(r, l)
+    tp.tri_pts[:] = snap_pts
+    bp.ba_resident = False
+    bp._BaProcessor__execute_bundle_adjustment()
+    assert bp.ba_last_action == "solve"
+    ref = (np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list]), tp.tri_pts[0:3].copy())
+    assert rel(got[0], ref[0]) < 1e-12 and rel(got[1], ref[1]) < 1e-12
+    bp.ba_release()
     # the reconstruction is close to the truth (0.3 px noise): gauge is free, so compare reprojection error
     cams = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list])
     rmse = sfm.scenes.reprojection_rmse(cams, tp.tri_pts[0:3], sc)

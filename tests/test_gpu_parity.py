@@ -232,21 +232,74 @@ def test_ba_vs_oracle_midsize_ragged(hip, oracle, sfm, mode):
 
 
 def test_ba_config3_full_size_vs_oracle(hip, oracle, sfm):
-    """BASELINE config 3 (50 x 20 000 @ 60 %): one iteration against the block-sparse oracle plus
-    size-independent properties: RMSE decreases monotonically over 3 iterations, quaternions stay unit,
-    and the two Schur kernels agree."""
+    """BASELINE config 3 (50 x 20 000 @ 60 %): 1, 2 and 3 iterations (the reference's default count,
+    ba_processor.py:24) against the block-sparse oracle for both Schur kernels, plus size-independent
+    properties: RMSE decreases monotonically, quaternions stay unit, and the two Schur kernels agree."""
     sc = sfm.scenes.make_config("C3", seed=0)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
-    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 1)
+    trace = []
+    oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3, trace=trace)
     results = {}
     for mode in (hip.SCHUR_MFMA, hip.SCHUR_PAIRS):
         with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
             prob.set_option(hip.OPT_SCHUR, mode)
             prob.set_state(sc.cams_init, sc.pts_init)
+            rm = [sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc)]
+            for it in range(3):
+                prob.iterate(5.0, 1)
+                c, p = prob.get_state()
+                assert rel(c, trace[it][0]) < TOL and rel(p, trace[it][1]) < TOL, (mode, it)
+                rm.append(sfm.scenes.reprojection_rmse(c, p, sc))
+            assert all(b < a for a, b in zip(rm, rm[1:])), rm
+            ro = sfm.scenes.reprojection_rmse(trace[2][0], trace[2][1], sc)
+            assert abs(rm[-1] - ro) / ro < 1e-9          # north-star contract is 1e-6
+            assert np.allclose(np.linalg.norm(c[:, 3:7], axis=1), 1.0, atol=1e-14)
+            results[mode] = (c, p)
+    assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_PAIRS][0]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_PAIRS][1]) < TOL
+
+
+# ---- BASELINE config 4: 200 cameras x 100 000 points @ 15 %, point blocks sharded over 8 GPUs ------------
+def test_ba_config4_one_gpu_share_vs_oracle(hip, oracle, sfm):
+    """One GPU's share of config 4 (200 cameras x 12 500 points @ 15 %, seed 0): 1, 2 and 3 iterations against the
+    block-sparse oracle, with the kernel AUTO picks at this size (the sparse LDS-tile product) and with the dense
+    MFMA product forced.  Covers the 44-step Cholesky, the big back substitution (7V = 1400 > 416) and the
+    global-accumulator mode of ba_linearize at the size the 8-GPU configuration runs them."""
+    sc = sfm.scenes.make_scene(200, 12500, 0.15, seed=0)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    trace = []
+    oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3, trace=trace)
+    for mode in (hip.SCHUR_AUTO, hip.SCHUR_MFMA):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, mode)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            for it in range(3):
+                prob.iterate(5.0, 1)
+                c, p = prob.get_state()
+                assert rel(c, trace[it][0]) < TOL and rel(p, trace[it][1]) < TOL, (mode, it)
+            if mode == hip.SCHUR_AUTO:
+                assert prob.info(hip.INFO_SCHUR_KERNEL) == hip.SCHUR_PAIRS
+    r3 = sfm.scenes.reprojection_rmse(c, p, sc)
+    ro = sfm.scenes.reprojection_rmse(trace[2][0], trace[2][1], sc)
+    assert abs(r3 - ro) / ro < 1e-9
+
+
+def test_ba_config4_full_size_one_gpu(hip, oracle, sfm):
+    """All of config 4 (200 x 100 000 @ 15 %, M = 3.0 M observations) resident on ONE GPU: one iteration against
+    the oracle (~30 s of NumPy), then the size-independent properties over 3 iterations -- monotone RMSE, unit
+    quaternions, dense MFMA product == sparse product to 1e-9."""
+    sc = sfm.scenes.make_config("C4", seed=0)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 1)
+    results = {}
+    for mode in (hip.SCHUR_PAIRS, hip.SCHUR_MFMA):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, mode)
+            prob.set_state(sc.cams_init, sc.pts_init)
             prob.iterate(5.0, 1)
-            cams1, pts1 = prob.get_state()
-            assert rel(cams1, ocams) < TOL and rel(pts1, opts) < TOL
-            rm = [sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc), sfm.scenes.reprojection_rmse(cams1, pts1, sc)]
+            c, p = prob.get_state()
+            assert rel(c, ocams) < TOL and rel(p, opts) < TOL, mode
+            rm = [sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc), sfm.scenes.reprojection_rmse(c, p, sc)]
             for _ in range(2):
                 prob.iterate(5.0, 1)
                 c, p = prob.get_state()

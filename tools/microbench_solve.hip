@@ -1,0 +1,193 @@
+// Latency microbenchmarks that size the reduced-solve kernel (gfx950; not part of the product):
+//   1. v_rsq_f64 / v_rcp_f64 seed precision, and after one / two Newton steps
+//   2. dependent-chain latency (shader cycles per link, one wave): v_fma_f64, rsqrt + 1 or 2 Newton steps,
+//      v_readlane -> VALU use, LDS write -> broadcast read
+//   3. cross-workgroup hand-off inside one launch: ping-pong of an 8-byte word and of an 8 KiB block + flag
+//      (relaxed agent-scope atomics = sc1 loads / stores, no fences), round trips per microsecond
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench_solve.hip -o gpurun_out/microbench_solve
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void k_precision(const double* in, double* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = in[i];
+  const double r0 = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  const double r1 = r0 * (1.5 - h * r0 * r0);
+  const double r2 = r1 * (1.5 - h * r1 * r1);
+  const double c0 = __builtin_amdgcn_rcp(d);
+  const double c1 = c0 * (2.0 - d * c0);
+  out[6 * i + 0] = r0; out[6 * i + 1] = r1; out[6 * i + 2] = r2;
+  out[6 * i + 3] = c0; out[6 * i + 4] = c1; out[6 * i + 5] = c1 * (2.0 - d * c1);
+}
+
+// one wave; MODE selects the chain; returns cycles per link in out[0]
+template <int MODE>
+__global__ void k_chain(double* out, unsigned long long* cyc, int iters, double seed) {
+  __shared__ double buf[64];
+  const int lane = threadIdx.x;
+  double x = seed + lane * 1e-9;
+  buf[lane] = x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 0) {
+      x = x * 1.0000001 + 1e-9;
+    } else if (MODE == 1) {        // rsqrt + 2 Newton steps, fed back
+      double r = __builtin_amdgcn_rsq(x);
+      const double h = 0.5 * x;
+      r = r * (1.5 - h * r * r);
+      r = r * (1.5 - h * r * r);
+      x = r + 1.0;
+    } else if (MODE == 2) {        // rsqrt + 1 Newton step
+      double r = __builtin_amdgcn_rsq(x);
+      const double h = 0.5 * x;
+      r = r * (1.5 - h * r * r);
+      x = r + 1.0;
+    } else if (MODE == 3) {        // readlane -> FMA
+      const int lo = __builtin_amdgcn_readlane(__double2loint(x), 5);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 5);
+      x = x * 0.5 + __hiloint2double(hi, lo) * 0.25;
+    } else if (MODE == 4) {        // LDS write -> uniform-address read (single wave: in order)
+      buf[lane] = x;
+      x = x * 0.5 + buf[7] * 0.25;
+    } else if (MODE == 5) {        // bare rsq
+      x = __builtin_amdgcn_rsq(x) + 1.0;
+    } else if (MODE == 6) {        // DPP row broadcast-like move -> FMA
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+      x = x * 0.5 + __hiloint2double(hi, lo) * 0.25;
+    }
+  }
+  asm volatile("" :: "v"(x));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[lane] = x;
+  if (lane == 0) cyc[0] = t1 - t0;
+}
+
+// ping-pong between workgroup 0 and workgroup `peer` (others idle-exit): `bytes` of payload (multiple of 8,
+// written by all 256 threads as 8-byte relaxed agent atomics = sc1), then the flag by thread 0 after a
+// vmcnt(0) drain + barrier; the receiver polls the flag (one lane, sc1 load), barrier, reads the payload sc1.
+typedef unsigned long long u64;
+__global__ void k_pingpong(u64* flags, double* payload, int words, int rounds, int peer, unsigned long long* cyc, double* sink) {
+  const int me = blockIdx.x == 0 ? 0 : (blockIdx.x == (unsigned)peer ? 1 : -1);
+  if (me < 0) return;
+  u64* my_flag = flags + 32 * me;          // separate 256-B lines
+  u64* other_flag = flags + 32 * (1 - me);
+  double* my_buf = payload + (size_t)me * 4096;
+  double* other_buf = payload + (size_t)(1 - me) * 4096;
+  double acc = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int r = 1; r <= rounds; ++r) {
+    if (me == 0) {
+      for (int i = threadIdx.x; i < words; i += blockDim.x) __hip_atomic_store(&my_buf[i], (double)(r + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(my_flag, (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(other_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (u64)r && ++spins < 20000000) {}
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < words; i += blockDim.x) acc += __hip_atomic_load(&other_buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (me == 1) {
+      for (int i = threadIdx.x; i < words; i += blockDim.x) __hip_atomic_store(&my_buf[i], (double)(r + i) + acc * 1e-300, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(my_flag, (u64)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && me == 0) cyc[0] = t1 - t0;      // 100 MHz ticks
+  sink[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+__global__ void k_empty(double* p) { if (p == nullptr) p[0] = 1; }
+
+int main() {
+  // ---- 1. precision ----
+  {
+    const int n = 1 << 20;
+    std::vector<double> h(n);
+    unsigned long long s = 88172645463325252ull;
+    for (int i = 0; i < n; ++i) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const double u = (double)(s >> 11) / 9007199254740992.0;
+      h[i] = std::exp((u - 0.5) * 40.0);      // 2e-9 .. 5e8
+    }
+    double *din, *dout;
+    CHECK(hipMalloc(&din, n * sizeof(double))); CHECK(hipMalloc(&dout, 6 * n * sizeof(double)));
+    CHECK(hipMemcpy(din, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    k_precision<<<n / 256, 256>>>(din, dout, n);
+    std::vector<double> o(6 * (size_t)n);
+    CHECK(hipMemcpy(o.data(), dout, o.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double e[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+      const long double d = h[i];
+      const long double rs = 1.0L / sqrtl(d), rc = 1.0L / d;
+      for (int k = 0; k < 3; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[6 * i + k] - rs) / rs));
+      for (int k = 3; k < 6; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[6 * i + k] - rc) / rc));
+    }
+    printf("v_rsq_f64 max rel err: seed %.3e  +1 Newton %.3e  +2 Newton %.3e\n", e[0], e[1], e[2]);
+    printf("v_rcp_f64 max rel err: seed %.3e  +1 Newton %.3e  +2 Newton %.3e\n", e[3], e[4], e[5]);
+  }
+  // ---- 2. chains ----
+  {
+    double* dout; unsigned long long* dc;
+    CHECK(hipMalloc(&dout, 64 * sizeof(double))); CHECK(hipMalloc(&dc, 8));
+    const char* names[] = {"v_fma_f64", "rsq + 2 Newton + add", "rsq + 1 Newton + add", "v_readlane x2 -> fma", "ds_write -> ds_read bcast -> fma", "v_rsq_f64 + add", "dpp x2 -> fma"};
+    const int iters = 20000;
+    for (int m = 0; m < 7; ++m) {
+      for (int rep = 0; rep < 2; ++rep) {
+        switch (m) {
+          case 0: k_chain<0><<<1, 64>>>(dout, dc, iters, 1.0); break;
+          case 1: k_chain<1><<<1, 64>>>(dout, dc, iters, 1.3); break;
+          case 2: k_chain<2><<<1, 64>>>(dout, dc, iters, 1.3); break;
+          case 3: k_chain<3><<<1, 64>>>(dout, dc, iters, 1.0); break;
+          case 4: k_chain<4><<<1, 64>>>(dout, dc, iters, 1.0); break;
+          case 5: k_chain<5><<<1, 64>>>(dout, dc, iters, 1.3); break;
+          default: k_chain<6><<<1, 64>>>(dout, dc, iters, 1.0); break;
+        }
+        CHECK(hipDeviceSynchronize());
+      }
+      unsigned long long c;
+      CHECK(hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost));
+      printf("chain %-34s %.1f s_memtime ticks per link\n", names[m], (double)c / iters);
+    }
+  }
+  // ---- 3. ping-pong ----
+  {
+    u64* flags; double* payload; unsigned long long* dc; double* sink;
+    CHECK(hipMalloc(&flags, 64 * sizeof(u64))); CHECK(hipMalloc(&payload, 2 * 4096 * sizeof(double)));
+    CHECK(hipMalloc(&dc, 8)); CHECK(hipMalloc(&sink, 256 * 256 * sizeof(double)));
+    const int rounds = 2000;
+    for (int peer : {1, 8, 9, 100}) {
+      for (int words : {0, 128, 1024}) {
+        CHECK(hipMemset(flags, 0, 64 * sizeof(u64)));
+        k_pingpong<<<256, 256>>>(flags, payload, words, rounds, peer, dc, sink);
+        CHECK(hipDeviceSynchronize());
+        unsigned long long c;
+        CHECK(hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost));
+        printf("ping-pong wg0 <-> wg%-3d payload %5d B: %.2f us per one-way hop\n", peer, words * 8, (double)c * 0.01 / rounds / 2);
+      }
+    }
+  }
+  // ---- 4. back-to-back launch gap ----
+  {
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    double* p; CHECK(hipMalloc(&p, 8));
+    for (int i = 0; i < 10; ++i) k_empty<<<12, 256>>>(p);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 1000; ++i) k_empty<<<12, 256>>>(p);
+    CHECK(hipEventRecord(b)); CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    printf("empty 12-WG kernels back to back: %.2f us each\n", ms);
+  }
+  return 0;
+}

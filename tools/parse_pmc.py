@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc passes into per-kernel HBM traffic per launch (profiles/traffic.json).
 
-    python tools/parse_pmc.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> [out.json]
+    python tools/parse_pmc.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> [out.json] [workload key]
+
+With a workload key (bench.py prints it as roofline.traffic's lookup key, e.g.
+"C3/50cams_20000pts_per_rank/ba_schur_mfma") the record is merged into out.json under that key, so one file holds
+the traffic of several workloads and bench.py never attributes one workload's bytes to another.
 
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section) and
 cdna_hip_programming.md section 7: FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC
@@ -49,6 +53,15 @@ def main():
     flat = {k: v["hbm_bytes_per_launch"] for k, v in res.items()}
     flat["_detail"] = res
     flat["_note"] = "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; gfx950 FETCH_SIZE counts 64 B per 128 B request"
+    if len(sys.argv) > 4:
+        key = sys.argv[4]
+        try:
+            with open(out) as fh:
+                doc = json.load(fh)
+        except Exception:
+            doc = {}
+        doc[key] = flat
+        flat = doc
     with open(out, "w") as fh:
         json.dump(flat, fh, indent=1, sort_keys=True)
     for k, v in res.items():
