@@ -41,6 +41,16 @@ extern "C" {
 #define SFM_Q1_PNP_ROW_OVERLAP  1  /* campose_processor.py:404-405: rows stored at [pt:pt+2] */
 #define SFM_Q2_LOC_JAC_SIGN     2  /* campose_processor.py:802-804: sign of the v-row of d/dC */
 #define SFM_QUIRKS_REFERENCE    3
+/* Q13 (documented, NOT reproducible, therefore not a selectable bit): the six-point DLT of the linear PnP
+ * (campose_processor.py:565-633) negates loc together with rot when det(rot) < 0 (campose:629-631).  rot and the
+ * null vector it comes from flip sign together, loc = rot @ -cam_mat[:, 3] / s does not -- so whether that branch
+ * is taken, and with it whether the returned centre is C or -C, depends on the arbitrary sign LAPACK gives the
+ * last right-singular vector.  Measured on the reference's own PnP fixture (tests/golden/g5_pnp.npz, 300 seeded
+ * hypotheses): the branch fires for about half of them and each of those scores <= 1 inlier in the reference.
+ * The device returns the sign-invariant centre for every hypothesis: identical (R, C, inlier count) wherever the
+ * reference did not take the branch, the correct pose where it did.  tests/test_gpu_linear_and_incremental.py
+ * asserts exactly that, hypothesis by hypothesis. */
+#define SFM_Q13_PNP_LOC_SIGN_UNDEFINED 0
 
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
 #define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, sparse LDS-tile product otherwise (fitted cost models) */
@@ -48,7 +58,7 @@ extern "C" {
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, results unchanged) */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
@@ -132,6 +142,12 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix /*[3][n]*/, const double* 
                           int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
                           double R_out[9], double C_out[3], int* inlier_mask /*[n]*/, int* n_inliers,
                           int* best_hypothesis);
+
+/* Parity hook: every hypothesis of the RANSAC above -- pose and inlier count of each six-point sample
+ * (campose_processor.py:524-560 loop body, 565-633). */
+int sfm_pnp_six_point_hypotheses(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
+                                 int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
+                                 double* R_out /*[n_hyp][9]*/, double* C_out /*[n_hyp][3]*/, int* counts /*[n_hyp]*/);
 
 /* ---- Two-view initialisation ------------------------------------------------- */
 /* EpipolarProcessor.determine_fundamental_mat (epipolar_processor.py:22-57 = __normalize 97-137,

@@ -15,16 +15,6 @@ sharding.py    point-range sharding of BA across ranks (one process per GPU, RCC
 geometry.py    host-side q<->R helpers (camera block packing, reference exceptions)
 scenes.py      seeded synthetic scenes of BASELINE.json's configs
 """
-from . import geometry, scenes  # noqa: F401
+from . import geometry, native, observations, processors, scenes, sharding  # noqa: F401
 
-__all__ = ["geometry", "scenes"]
-
-for _name in ("native", "observations", "processors", "sharding"):
-    try:
-        _mod = __import__(__name__ + "." + _name, fromlist=[_name])
-    except ModuleNotFoundError as _e:          # module not written yet in this checkout
-        if _e.name != __name__ + "." + _name:
-            raise
-        continue
-    globals()[_name] = _mod
-    __all__.append(_name)
+__all__ = ["geometry", "native", "observations", "processors", "scenes", "sharding"]

@@ -14,12 +14,39 @@ constexpr int kSchurRB = 128;
 constexpr int kSchurKSL = 16;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
 constexpr int kLinGridPerCu = 3; // ba_linearize workgroups per CU (132 VGPRs -> 3 waves/SIMD; forcing 4 measured 10 % slower)
 
+// ---------------------------------------------------------------------------------------------
+// Layout of the reduced camera system [S | rhs] (BaDev::red), the buffer one all-reduce covers in the
+// multi-GPU split.  S is symmetric and only its lower triangle is ever formed, so only the lower-triangular
+// 32x32 BLOCKS are stored, block (br, bc), bc <= br, at ((br (br + 1)) / 2 + bc) * 1024 doubles, row-major inside
+// the block (element (i, k) at 32 i + k): 8.1 MB at V = 200 where the full square was 15.9 MB (0.54 MB vs 0.99 MB
+// at V = 50).  rhs (padded to 32 nbk) follows the blocks.  Entries above the diagonal inside diagonal blocks and
+// everything beyond P = 7V stay zero (the buffer is cleared once per iteration).
+//
+// The factorisation overwrites block (r, j) with L[r][j] in a DIFFERENT, k-interleaved order (red_lblk_off): lane
+// (row i, k-phase lk = k & 3) of a v_mfma_f64_16x16x4 A / B operand consumes k = lk, lk + 4, ..., lk + 28 over the
+// eight k-steps of a 32-deep product; that is four 16-byte pairs (k, k + 4), and pair m of the sixteen rows of a
+// tile is 256 contiguous bytes, so the block products of the later steps load their operands straight from global
+// memory with four fully coalesced 16-byte loads per tile and never stage them in LDS.  A row of L is written
+// as sixteen such pairs, coalesced across the 32 rows; columns c and c + 4 of one block row are neighbours as
+// well (what the back substitution reads).  Nothing outside sfm_ba_solve.hip sees that order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNB = 32;
+constexpr int kBlk = kNB * kNB;
+__host__ __device__ inline size_t red_blk_base(int br, int bc) { return ((size_t)br * (br + 1) / 2 + bc) * kBlk; }
+__host__ __device__ inline int red_blk_off(int i, int k) { return i * kNB + k; }
+__host__ __device__ inline int red_lblk_off(int i, int k) { return (k >> 3) * 256 + (k & 3) * 64 + i * 2 + ((k >> 2) & 1); }
+__host__ __device__ inline size_t red_index(int row, int col) {      // row >= col
+  return red_blk_base(row >> 5, col >> 5) + red_blk_off(row & 31, col & 31);
+}
+__host__ __device__ inline size_t red_rhs_off(int nbk) { return (size_t)nbk * (nbk + 1) / 2 * kBlk; }
+__host__ __device__ inline size_t red_size(int nbk) { return red_rhs_off(nbk) + (size_t)nbk * kNB; }
+
 // Plain-data view passed by value to kernels (all pointers are device memory).
 struct BaDev {
   int V = 0, N = 0;
   long long M = 0;
   int P = 0;    // 7 V
-  int ld = 0;   // leading dimension of S (P rounded up to 64)
+  int nbk = 0;  // 32-wide block rows / columns of S: ceil(P / 32)
   // static structure: observations sorted by (point, camera)
   int* pt_ptr = nullptr;    // [N+1]
   int* cam_idx = nullptr;   // [M]
@@ -39,8 +66,8 @@ struct BaDev {
   int zp = 0;               // row pitch of Zd = 128 * ceil(V / 18)
   int zrows = 0;            // 3N rounded up to a multiple of kSchurKSL
   double* lin_ws = nullptr; // [linearize workgroups][V][35] per-workgroup camera accumulators (U lower 28 | rhs 7)
-  double* red = nullptr;    // [ld*ld + ld] reduced system S | rhs (lower triangle of S valid)
-  double* delta = nullptr;  // [ld] camera update
+  double* red = nullptr;    // [red_size(nbk)] reduced system S (lower-triangular 32x32 blocks) | rhs
+  double* delta = nullptr;  // [32 nbk] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
@@ -58,13 +85,13 @@ __device__ __forceinline__ void cam_reduce_slice(const BaDev& d, int nrows, int 
   if (s == 0.0) return;
   const int c = t / 35, e = t % 35;
   double* S = d.red;
-  double* rhs = d.red + (size_t)d.ld * d.ld;
+  double* rhs = d.red + red_rhs_off(d.nbk);
   if (e >= 28) {
     atomicAdd(&rhs[7 * c + (e - 28)], s);
   } else {
     int i = 0, base = 0;                   // e = i(i+1)/2 + j
     while (base + i + 1 <= e) { base += i + 1; ++i; }
-    atomicAdd(&S[(size_t)(7 * c + i) * d.ld + 7 * c + (e - base)], s);
+    atomicAdd(&S[red_index(7 * c + i, 7 * c + (e - base))], s);
   }
 }
 
@@ -86,6 +113,8 @@ struct sfm_ba_problem {
   bool prep_valid = false;
   int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
+  bool backsub_pending = false;   // the reduced solve ran, its back substitution waits for the fused launch
+  bool lin_pending = false;       // inside ba_enqueue_iterations: the next iteration is already linearised
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
   int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight
@@ -107,8 +136,11 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
-int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool fused_backsub = false);
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks, bool defer_backsub = false);
+int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
+bool ba_can_fuse(const sfm_ba_problem* p);
+int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);
 void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out);
 }  // namespace sfm

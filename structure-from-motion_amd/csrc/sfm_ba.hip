@@ -60,10 +60,16 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // ba_linearize: G lanes per point (G = power of two <= 64 chosen from the mean track length).
 // LDS_MODE 2: [V][19] prepared cameras + [V][35] camera-side accumulators in LDS (V <= 151);
 // LDS_MODE 1: accumulators only, cameras read from global/L2 (V <= 234); LDS_MODE 0: global atomics.
-// ---------------------------------------------------------------------------------------------
 // DENSE_Z: Z_o goes to its 7x3 slot of the dense Zd (MFMA product); otherwise to the AoS Z of the sparse product.
-template <int G, int LDS_MODE, bool DENSE_Z>
+// FUSED (LDS_MODE 2 only): the back substitution of the PREVIOUS iteration runs first, on the same lanes and the
+// same 20 bytes per observation: dX_p = V_p^-1 (g_p - sum_o W_o^T dp_c) at the old cameras prep[cur ^ 1] and the old
+// point, X += dX (ba:405-406), then the linearisation at the new cameras prep[cur] and the new point -- one pass
+// over the observation list per iteration instead of two (ba_backsub + ba_linearize).  The kernel also clears
+// [S | rhs], which is dead once the reduced solve has run.
+// ---------------------------------------------------------------------------------------------
+template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED>
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
+  static_assert(!FUSED || LDS_MODE == 2, "the fused kernel keeps both camera sets in LDS");
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
   int sidx = 0;
@@ -71,21 +77,32 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
   constexpr bool PREP_LDS = LDS_MODE == 2, ACC_LDS = LDS_MODE >= 1;
   double* lds_prep = lds;                                        // V * 19 (mode 2)
   double* lds_acc = lds + (PREP_LDS ? (size_t)d.V * 19 : 0);     // V * 35
+  double* lds_old = lds + (size_t)d.V * (19 + 35);               // V * 19 (FUSED): cameras the last step linearised at
+  double* lds_delta = lds_old + (size_t)d.V * 19;                // V * 7  (FUSED): their update
   const CamPrep* gprep = d.prep[cur];
   if (ACC_LDS) {
     if (PREP_LDS) {
       const double* src = reinterpret_cast<const double*>(gprep);
       for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_prep[i] = src[i];
     }
+    if (FUSED) {
+      const double* src = reinterpret_cast<const double*>(d.prep[cur ^ 1]);
+      for (int i = threadIdx.x; i < d.V * 19; i += blockDim.x) lds_old[i] = src[i];
+      for (int i = threadIdx.x; i < d.V * 7; i += blockDim.x) lds_delta[i] = d.delta[i];
+    }
     for (int i = threadIdx.x; i < d.V * 35; i += blockDim.x) lds_acc[i] = 0.0;
     __syncthreads();
+  }
+  if (FUSED) {
+    const size_t n_red = red_size(d.nbk);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_red; i += (size_t)gridDim.x * blockDim.x) d.red[i] = 0.0;
   }
   if (stamp) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   constexpr int GPB = 256 / G;                 // point groups per block
   const int lane_g = threadIdx.x % G;
   const int grp = threadIdx.x / G;
   double* S = d.red;
-  double* rhs = d.red + (size_t)d.ld * d.ld;
+  double* rhs = d.red + red_rhs_off(d.nbk);
 
   for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
     const int p = p0 + grp;
@@ -95,14 +112,52 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
       beg = d.pt_ptr[p]; end = d.pt_ptr[p + 1];
       X = d.px[p]; Y = d.py[p]; Z = d.pz[p];
     }
-    double v6[6] = {0, 0, 0, 0, 0, 0}, g3[3] = {0, 0, 0};
+    const bool single = (end - beg) <= G;       // the whole track fits the lane group: every lane keeps its observation
     double r[2], Jp[14], Jx[6];
     int cam = 0;
-    for (int o = beg + lane_g; o < end; o += G) {
-      cam = d.cam_idx[o];
+    double uo = 0, vo = 0;
+    const int o1 = beg + lane_g;
+    if (single && o1 < end) { cam = d.cam_idx[o1]; uo = d.u[o1]; vo = d.v[o1]; }
+    if (FUSED) {
+      double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // v6 | (g - W^T dp)
+      for (int o = o1; o < end; o += G) {
+        if (!single) { cam = d.cam_idx[o]; uo = d.u[o]; vo = d.v[o]; }
+        CamPrep c;
+        load_cam(c, reinterpret_cast<const CamPrep*>(lds_old) + cam);
+        obs_terms(c, X, Y, Z, uo, vo, quirks, r, Jp, Jx);
+        const double* dp = lds_delta + 7 * cam;
+        double e0 = r[0], e1 = r[1];               // r - Jp dp
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { e0 -= Jp[i] * dp[i]; e1 -= Jp[7 + i] * dp[i]; }
+        a[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
+        a[1] += Jx[1] * Jx[0] + Jx[4] * Jx[3];
+        a[2] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
+        a[3] += Jx[2] * Jx[0] + Jx[5] * Jx[3];
+        a[4] += Jx[2] * Jx[1] + Jx[5] * Jx[4];
+        a[5] += Jx[2] * Jx[2] + Jx[5] * Jx[5];
+        a[6] += Jx[0] * e0 + Jx[3] * e1;
+        a[7] += Jx[1] * e0 + Jx[4] * e1;
+        a[8] += Jx[2] * e0 + Jx[5] * e1;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a[k] = group_sum<G>(a[k]);
+      a[0] += lambda; a[2] += lambda; a[5] += lambda;
+      double li[6];
+      chol3_inv_fast(a, li);
+      const double y0 = li[0] * a[6];
+      const double y1 = li[1] * a[6] + li[2] * a[7];
+      const double y2 = li[3] * a[6] + li[4] * a[7] + li[5] * a[8];
+      X += li[0] * y0 + li[1] * y1 + li[3] * y2;     // L^-T y, the same expression on every lane of the group
+      Y += li[2] * y1 + li[4] * y2;
+      Z += li[5] * y2;
+      if (lane_g == 0 && p < d.N) { d.px[p] = X; d.py[p] = Y; d.pz[p] = Z; }
+    }
+    double v6[6] = {0, 0, 0, 0, 0, 0}, g3[3] = {0, 0, 0};
+    for (int o = o1; o < end; o += G) {
+      if (!single) { cam = d.cam_idx[o]; uo = d.u[o]; vo = d.v[o]; }
       CamPrep c;
       load_cam(c, PREP_LDS ? reinterpret_cast<const CamPrep*>(lds_prep) + cam : gprep + cam);
-      obs_terms(c, X, Y, Z, d.u[o], d.v[o], quirks, r, Jp, Jx);
+      obs_terms(c, X, Y, Z, uo, vo, quirks, r, Jp, Jx);
       v6[0] += Jx[0] * Jx[0] + Jx[3] * Jx[3];
       v6[1] += Jx[1] * Jx[0] + Jx[4] * Jx[3];
       v6[2] += Jx[1] * Jx[1] + Jx[4] * Jx[4];
@@ -129,8 +184,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     const double h1 = li[2] * y1 + li[4] * y2;
     const double h0 = li[0] * y0 + li[1] * y1 + li[3] * y2;
     if (stamp && sidx < 60) { asm volatile("" :: "v"(h0)); stamp[sidx++] = __builtin_amdgcn_s_memtime(); }
-    const bool single = (end - beg) <= G;
-    for (int o = beg + lane_g; o < end; o += G) {
+    for (int o = o1; o < end; o += G) {
       if (!single) {
         cam = d.cam_idx[o];
         CamPrep c;
@@ -194,7 +248,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
       } else {
         k = 0;
         for (int i = 0; i < 7; ++i)
-          for (int j = 0; j <= i; ++j) { atomicAdd(&S[(size_t)(7 * cam + i) * d.ld + 7 * cam + j], acc[k]); ++k; }
+          for (int j = 0; j <= i; ++j) { atomicAdd(&S[red_index(7 * cam + i, 7 * cam + j)], acc[k]); ++k; }
         for (int i = 0; i < 7; ++i) atomicAdd(&rhs[7 * cam + i], acc[28 + i]);
       }
     }
@@ -233,7 +287,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev d, int cur, doubl
   // [S | rhs] is dead once ba_back_solve has run: clear it here (a few hundred bytes per workgroup) so the
   // next iteration's linearisation needs no separate memset
   {
-    const size_t n_red = (size_t)d.ld * d.ld + d.ld;
+    const size_t n_red = red_size(d.nbk);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_red; i += (size_t)gridDim.x * blockDim.x) d.red[i] = 0.0;
   }
   for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
@@ -298,392 +352,6 @@ __global__ void ba_residual_jacobian_kernel(BaDev d, int cur, int quirks, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Reduced solve.  S + lambda I = L L^T by a blocked right-looking Cholesky on 32x32 blocks, one launch
-// per block column j.  Workgroup (r, c), j <= c <= r, first applies the previous panel's update
-// A[r][c] -= L[r][j-1] L[c][j-1]^T (K = 32, all 256 threads).  Blocks right of column j store the
-// result and leave.  Blocks in column j then need the factor of the diagonal block: every one of them
-// recomputes D = A[j][j] - L[j][j-1] L[j][j-1]^T + lambda I locally (nobody writes S(j,j) in this
-// launch, so there is no race) and hands [D; T] to ONE wave that runs a register-resident elimination
-// with lanes 0..31 = rows of D and lanes 32..63 = rows of T: the column steps that factor D
-// (l_jj = sqrt(d_jj), rank-1 trailing update, operands broadcast with v_readlane) perform the
-// triangular solve X L_d^T = T on the other 32 lanes in the same instruction stream.  The rhs vector
-// rides along as block row `nbk` (one valid row), so L y = rhs needs no pass of its own.
-// L overwrites the strictly-lower blocks of S in place; diagonal factors go to d.ldiag.
-// ---------------------------------------------------------------------------------------------
-constexpr int NB = 32;
-
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-// One wave: a[] = this lane's row (lanes 0..31: rows of the SPD block D, lower part valid; lanes
-// 32..63: rows of T).  On return lanes 0..31 hold the rows of L_d (lower) and lanes 32..63 the rows of
-// X = T L_d^-T.  Column j of L_d is published through a 32-double LDS buffer and read back with
-// wave-uniform addresses (LDS broadcast): one ds_read + one FMA per trailing entry, no SGPR hazards.
-// Single wave => its LDS operations execute in order; no barrier is needed.
-__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], double (*colbuf)[64], int lane) {
-  // Software-pipelined over columns.  Per column j:
-  //   1. pivot chain: inv = rsqrt(d_jj), scale column j                       (critical path)
-  //   2. deferred bulk update with column j-1, whose entries were read back from LDS one step ago
-  //   3. fast path: the FAST trailing columns the next pivots depend on, through register broadcasts
-  //   4. publish column j in its own LDS row (all 64 lanes store: no exec masking, one basic block) and
-  //      issue the LDS reads whose values step j+1 consumes in (2)
-  // Every LDS row is written once and read once, so there are no WAR hazards for the scheduler to respect.
-  constexpr int FAST = 2;
-  double lk[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) lk[k] = 0.0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double inv = rsqrt_nr(lane_bcast(a[j], j));
-    if (j > 0) {
-#pragma unroll
-      for (int k = j + FAST; k < NB; ++k) a[k] -= a[j - 1] * lk[k];      // column j-1, entries k >= (j-1)+1+FAST
-    }
-    a[j] *= inv;
-#pragma unroll
-    for (int k = j + 1; k < NB && k <= j + FAST; ++k) a[k] -= a[j] * lane_bcast(a[j], k);
-    colbuf[j][lane] = a[j];
-#pragma unroll
-    for (int k = j + 1 + FAST; k < NB; ++k) lk[k] = colbuf[j][k];
-  }
-}
-
-typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
-constexpr int LP = NB + 2;   // LDS pitch 34 doubles: the (row, k) operand reads of v_mfma_f64_16x16x4 hit 32 distinct bank pairs
-
-// Trailing role of a column step: a 64x64 super-tile (2x2 blocks, one block per wave) of the blocks right of
-// column j gets the previous panel's update A[r][c] -= L[r][j-1] L[c][j-1]^T on the matrix pipe.  Four times
-// fewer workgroups than one per block and each L tile is loaded once for two blocks, which is what matters
-// when 7V is in the thousands (V = 200: ~1000 blocks per step).
-__device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, int sr, int sc, double (*La2)[LP],
-                                                        double (*Lb2)[LP]) {
-  const int P = d.P, ld = d.ld;
-  const int nbk = (P + NB - 1) / NB;
-  double* S = d.red;
-  double* rhs = d.red + (size_t)ld * ld;
-  const int k0 = (j - 1) * NB;
-  const int rbase = j + 1 + 2 * sr, cbase = j + 1 + 2 * sc;       // block indices of the super-tile's corner
-  const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int br = wave >> 1, bc = wave & 1;
-  const int r = rbase + br, c = cbase + bc;
-  const bool valid = c <= nbk - 1 && r >= c && r <= nbk;
-  const bool is_rhs = r == nbk;
-  const int lr = lane & 15, lk = lane >> 4;
-  // old block values in the MFMA C/D layout (issued before the LDS hand-over so they overlap it)
-  double old[2][2][4];
-  if (valid) {
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int i = 16 * sx + lk + 4 * g;
-          const double* pr = is_rhs ? rhs : S + (size_t)(r * NB + i) * ld;
-          old[sx][sy][g] = pr[c * NB + 16 * sy + lr];
-        }
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int i = ti + 8 * e;                 // 0..63: two stacked blocks
-    const int rb = rbase + (i >> 5), cb = cbase + (i >> 5), ii = i & 31;
-    const double* pa = rb == nbk ? rhs : S + (size_t)(min(rb, nbk - 1) * NB + ii) * ld;
-    const double va = pa[k0 + tj];
-    La2[i][tj] = (rb < nbk || (rb == nbk && ii == 0)) ? va : 0.0;
-    const double vb = S[(size_t)(min(cb, nbk - 1) * NB + ii) * ld + k0 + tj];
-    Lb2[i][tj] = cb <= nbk - 1 ? vb : 0.0;
-  }
-  __syncthreads();
-  if (!valid) return;
-  chol_f64x4 acc[2][2];
-#pragma unroll
-  for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = chol_f64x4{0, 0, 0, 0};
-#pragma unroll
-  for (int kk = 0; kk < NB; kk += 4) {
-    const double a0 = La2[32 * br + lr][kk + lk], a1 = La2[32 * br + 16 + lr][kk + lk];
-    const double b0 = Lb2[32 * bc + lr][kk + lk], b1 = Lb2[32 * bc + 16 + lr][kk + lk];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
-#pragma unroll
-  for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i = 16 * sx + lk + 4 * g, col = c * NB + 16 * sy + lr;
-        const bool row_ok = is_rhs ? (i == 0) : (r * NB + i < P);
-        if (row_ok && col < P) (is_rhs ? rhs : S + (size_t)(r * NB + i) * ld)[col] = old[sx][sy][g] - acc[sx][sy][g];
-      }
-}
-
-__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
-  // one LDS arena, carved per role
-  constexpr int kTile = NB * LP, kSq = NB * (NB + 1);
-  __shared__ double arena[3 * kTile + 2 * kSq + NB * 64];
-  const int P = d.P, ld = d.ld;
-  const int nbk = (P + NB - 1) / NB;
-  // workgroups 0 .. nbk-j are the column role (block rows j .. nbk, the last one being the rhs row); the rest
-  // are trailing super-tiles (sr >= sc) with two 64 x 34 operand tiles
-  const int ncol = nbk - j + 1;
-  if ((int)blockIdx.x >= ncol) {
-    int t = blockIdx.x - ncol, sr = 0;
-    while (t > sr) { t -= sr + 1; ++sr; }
-    static_assert(4 * kTile <= 3 * kTile + 2 * kSq + NB * 64, "trailing tiles must fit the arena");
-    chol_trailing_supertile(d, j, sr, t, reinterpret_cast<double(*)[LP]>(arena),
-                            reinterpret_cast<double(*)[LP]>(arena + 2 * kTile));
-    return;
-  }
-  double(*La)[LP] = reinterpret_cast<double(*)[LP]>(arena);                  // L[r][j-1]
-  double(*Lb)[LP] = reinterpret_cast<double(*)[LP]>(arena + kTile);          // L[c][j-1]
-  double(*Lj)[LP] = reinterpret_cast<double(*)[LP]>(arena + 2 * kTile);      // L[j][j-1] (blocks with r != j)
-  double(*Tm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + 3 * kTile);
-  double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + 3 * kTile + kSq);
-  double(*colbuf)[64] = reinterpret_cast<double(*)[64]>(arena + 3 * kTile + 2 * kSq);   // one row per elimination column
-  const int c = j, r = j + blockIdx.x;
-  const bool is_rhs = r == nbk;
-  // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
-  unsigned long long* stamp = (d.stamps && blockIdx.x == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
-  if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
-  double* S = d.red;
-  double* rhs = d.red + (size_t)ld * ld;
-  const int r0 = r * NB, c0 = c * NB, j0 = j * NB, k0 = (j - 1) * NB;
-  const int tid = threadIdx.x, ti = tid / NB, tj = tid % NB;
-  const int lane = tid & 63, wave = tid >> 6;
-  const bool need_d = r != j;
-
-  // This wave's 16x16 part of the 32x32 block, in the C/D layout of v_mfma_f64_16x16x4_f64:
-  // element reg of lane l is (row = 16 sx + (l >> 4) + 4 reg, col = 16 sy + (l & 15)).
-  const int sx = wave >> 1, sy = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ocol = 16 * sy + lr;
-  const bool col_ok = c0 + ocol < P;
-
-  // Every global load of the step is issued unconditionally and before the first wait: S has ld >= 32 nbk
-  // rows and columns and is zero outside P x P (memset per iteration, never written there), so padded
-  // rows / columns simply read as zero; the 31 non-existent rows of the rhs block are masked by a select.
-  double aT[4], aD[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int i = 16 * sx + lk + 4 * g;
-    const double* pr = is_rhs ? rhs : S + (size_t)(r0 + i) * ld;
-    const double t = pr[c0 + ocol];
-    aT[g] = (!is_rhs || i == 0) ? t : 0.0;
-    if (need_d) aD[g] = S[(size_t)(j0 + i) * ld + j0 + ocol];
-  }
-  if (j > 0) {
-    double la[4], lb[4], lj[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      const double* pr = is_rhs ? rhs : S + (size_t)(r0 + i) * ld;
-      const double a = pr[k0 + tj];
-      la[e] = (!is_rhs || i == 0) ? a : 0.0;
-      lb[e] = S[(size_t)(c0 + i) * ld + k0 + tj];
-      if (need_d) lj[e] = S[(size_t)(j0 + i) * ld + k0 + tj];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = ti + 8 * e;
-      La[i][tj] = la[e];
-      Lb[i][tj] = lb[e];
-      if (need_d) Lj[i][tj] = lj[e];
-    }
-    __syncthreads();
-    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
-    // previous-panel update on the matrix pipe: T -= L[r][j-1] L[c][j-1]^T, D -= L[j][j-1] L[j][j-1]^T.
-    // A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15] = Lb[col][k].
-    chol_f64x4 pT = {0, 0, 0, 0}, pD = {0, 0, 0, 0};
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4)
-      pT = __builtin_amdgcn_mfma_f64_16x16x4f64(La[16 * sx + lr][kk + lk], Lb[16 * sy + lr][kk + lk], pT, 0, 0, 0);
-    if (need_d) {
-#pragma unroll
-      for (int kk = 0; kk < NB; kk += 4)
-        pD = __builtin_amdgcn_mfma_f64_16x16x4f64(Lj[16 * sx + lr][kk + lk], Lj[16 * sy + lr][kk + lk], pD, 0, 0, 0);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { aT[g] -= pT[g]; aD[g] -= pD[g]; }
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int i = 16 * sx + lk + 4 * g;
-    const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
-    double t = (row_ok && col_ok) ? aT[g] : 0.0;
-    if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
-      if (i == ocol) t = col_ok ? t + lambda : 1.0;
-      Dm[i][ocol] = t;
-      Tm[i][ocol] = (i == ocol) ? 1.0 : 0.0;     // the T half of the diagonal workgroup carries I: X = L_d^-T for free
-    } else {
-      Tm[i][ocol] = t;
-      double dv = (j0 + i < P && col_ok) ? aD[g] : 0.0;
-      if (i == ocol) dv = col_ok ? dv + lambda : 1.0;
-      Dm[i][ocol] = dv;
-    }
-  }
-  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
-  __syncthreads();
-  if (tid >= 64) return;
-  double a[NB];
-  const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
-  const int row = lane & (NB - 1);
-#pragma unroll
-  for (int k = 0; k < NB; ++k) a[k] = src[row][k];
-  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
-  chol_trsm_rows(a, colbuf, lane);
-  if (stamp) { asm volatile("" :: "v"(a[NB - 1])); stamp[4] = __builtin_amdgcn_s_memtime(); }
-  if (r == j) {
-    if (lane >= NB) {
-      // row `row` of X = L_d^-T (upper triangular), stored k-major so that the back substitution's lane i reads
-      // its row with coalesced loads: ldiag[j][k][i] = X[i][k]
-      double* out = d.ldiag + (size_t)j * NB * NB + row;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) out[k * NB] = (k >= row) ? a[k] : 0.0;
-    }
-  } else if (lane >= NB) {
-    if (is_rhs) {
-      if (row == 0) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) if (c0 + k < P) rhs[c0 + k] = a[k];
-      }
-    } else if (r0 + row < P) {
-      double* out = S + (size_t)(r0 + row) * ld + c0;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) out[k] = a[k];
-    }
-  }
-  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
-}
-
-// L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one workgroup:
-// per block, wave 0 computes x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the factorisation left
-// in ldiag (lane i holds row i; the next block's factor is prefetched) while the other waves hold the L rows of
-// the blocks above in registers (two adjacent rows per thread, 32 independent 16-byte loads issued before x_b
-// exists) and fold x_b into their y.  Then the camera update of ba:383-392 and the preparation of the next
-// iteration.
-// Rows beyond the 384 that ba_back_solve's update waves hold in registers; only the BIG instantiation
-// (7V > 416) contains it, so the small-system kernel keeps its register allocation.
-template <bool Y_LDS>
-__device__ __forceinline__ void back_solve_far_rows(const double* __restrict__ S, int ld, int c0, int utid,
-                                                              const double* xb, double* y) {
-  for (int i = utid + 384; i < c0; i += 192) {
-    double w[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) w[k] = S[(size_t)(c0 + k) * ld + i];
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) s += w[k] * xb[k];
-    y[i] -= s;
-  }
-}
-
-template <bool Y_LDS, bool BIG>
-__global__ __launch_bounds__(256) void ba_back_solve_kernel(BaDev d, int cur) {
-  extern __shared__ double ylds[];     // [ld] working copy of y when it fits (Y_LDS)
-  __shared__ double xb[NB];
-  const int P = d.P, ld = d.ld;
-  const double* S = d.red;
-  double* yg = d.red + (size_t)ld * ld;
-  const int tid = threadIdx.x;
-  const int lane = tid & (NB - 1);
-  const int nbk = (P + NB - 1) / NB;
-  if (Y_LDS) {
-    for (int i = tid; i < ld; i += blockDim.x) ylds[i] = yg[i];
-  }
-  auto yref = [&](int i) -> double& { return Y_LDS ? ylds[i] : yg[i]; };
-  // wave 0 owns the diagonal blocks: x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the
-  // factorisation left in ldiag (lane i holds row i, static register indexing; no sequential column chain);
-  // waves 1-3 fold x_b into the y of the blocks above, their 32 independent coalesced row loads per thread
-  // issued before x_b exists
-  __shared__ double yb[NB];
-  double col[NB];
-  if (tid < 64) {
-    const double* Xd = d.ldiag + (size_t)(nbk - 1) * NB * NB;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) col[k] = Xd[k * NB + lane];      // row `lane` of L_d^-T
-  }
-  __syncthreads();
-  unsigned long long* stamp = (d.stamps && tid == 0) ? d.stamps + 128 : nullptr;
-  const int utid = tid - 64;            // 0..191 for the update waves
-  for (int b = nbk - 1; b >= 0; --b) {
-    const int c0 = b * NB;
-    if (stamp) stamp[4 * b + 0] = __builtin_amdgcn_s_memtime();
-    double v[2][NB];
-    if (tid >= 64) {
-      // this thread's two ADJACENT rows 2 utid, 2 utid + 1 as one 16-byte load per k (half the requests of
-      // two 8-byte loads: the hand-over to wave 0 waits for exactly these loads)
-      if (2 * utid < c0) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-          const double2 t = *reinterpret_cast<const double2*>(&S[(size_t)(c0 + k) * ld + 2 * utid]);   // rows >= P are zero
-          v[0][k] = t.x; v[1][k] = t.y;
-        }
-      }
-    } else {
-      if (tid < NB) yb[lane] = (c0 + lane < P) ? yref(c0 + lane) : 0.0;      // single wave: LDS in order
-      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-#pragma unroll
-      for (int k = 0; k < NB; k += 4) {
-        x0 += col[k] * yb[k]; x1 += col[k + 1] * yb[k + 1]; x2 += col[k + 2] * yb[k + 2]; x3 += col[k + 3] * yb[k + 3];
-      }
-      const double xi = (x0 + x1) + (x2 + x3);
-      if (tid < NB) {
-        xb[lane] = (c0 + lane < P) ? xi : 0.0;
-        if (c0 + lane < P) d.delta[c0 + lane] = xi;
-      }
-      if (stamp) stamp[4 * b + 1] = __builtin_amdgcn_s_memtime();
-      if (b > 0) {                       // next diagonal factor; lands during the update below
-        const double* Xd = d.ldiag + (size_t)(b - 1) * NB * NB;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) col[k] = Xd[k * NB + lane];
-      }
-    }
-    __syncthreads();
-    if (stamp) stamp[4 * b + 2] = __builtin_amdgcn_s_memtime();
-    if (tid >= 64) {
-      if (2 * utid < c0) {
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) { s0 += v[0][k] * xb[k]; s1 += v[1][k] * xb[k]; }
-        yref(2 * utid) -= s0;
-        yref(2 * utid + 1) -= s1;
-      }
-      if (BIG) back_solve_far_rows<Y_LDS>(S, ld, c0, utid, xb, Y_LDS ? ylds : yg);
-    }
-    __syncthreads();
-    if (stamp) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
-  }
-  for (int c = tid; c < d.V; c += blockDim.x) {
-    double cam[7];
-    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383
-    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
-    for (int k = 3; k < 7; ++k) cam[k] /= nq;
-    for (int k = 0; k < 7; ++k) d.cams[7 * c + k] = cam[k];
-    CamPrep out;
-    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
-    d.prep[cur ^ 1][c] = out;
-    report_status(d.status, st, c);
-  }
-}
-
-// S (lower) -> dense symmetric host-visible copy for the parity hook.
-__global__ void ba_symmetrize_kernel(const double* __restrict__ S, int ld, int P, double lambda, double* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P * P) return;
-  const int i = idx / P, j = idx % P;
-  const int a = max(i, j), b = min(i, j);
-  out[idx] = S[(size_t)a * ld + b] + (i == j ? lambda : 0.0);
-}
-
-// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static int pick_group(const sfm_ba_problem* p) {
@@ -694,15 +362,16 @@ static int pick_group(const sfm_ba_problem* p) {
   return g;
 }
 
-template <int LDS, bool WZ>
-static void launch_linearize(const sfm_ba_problem* p, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
+// `cur` = prep slot of the cameras to linearise at (FUSED: the back substitution uses the other slot)
+template <int LDS, bool WZ, bool FUSED = false>
+static void launch_linearize(const sfm_ba_problem* p, int cur, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
   const BaDev& d = p->dev;
   switch (g) {
-    case 4: ba_linearize_kernel<4, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 8: ba_linearize_kernel<8, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 16: ba_linearize_kernel<16, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    case 32: ba_linearize_kernel<32, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
-    default: ba_linearize_kernel<64, LDS, WZ><<<grid, 256, lds, s>>>(d, p->cur, lambda, quirks); break;
+    case 4: ba_linearize_kernel<4, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
+    case 8: ba_linearize_kernel<8, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
+    case 16: ba_linearize_kernel<16, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
+    case 32: ba_linearize_kernel<32, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
+    default: ba_linearize_kernel<64, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
   }
 }
 
@@ -745,11 +414,23 @@ int ba_enqueue_prep(sfm_ba_problem* p) {
   return SFM_OK;
 }
 
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+// The fused kernel keeps both camera sets, the camera update and the camera accumulators in LDS: 80 doubles per
+// camera (V <= 102 within the 64 KB the other kernels of the iteration leave room for).
+bool ba_can_fuse(const sfm_ba_problem* p) {
+  return !(p->debug & 16) && sizeof(double) * (size_t)p->dev.V * (19 + 35 + 19 + 7) <= 64 * 1024;
+}
+
+// fused_backsub: the reduced solve of the previous iteration has run with its back substitution deferred
+// (ba_enqueue_solve_update(..., true)); this launch finishes that iteration and linearises the next one.
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool fused_backsub) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
-  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
-  if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * ((size_t)d.ld * d.ld + d.ld), s));
+  if (fused_backsub) {
+    if (!p->backsub_pending || !ba_can_fuse(p)) { set_error("internal: fused linearisation without a deferred back substitution"); return SFM_E_HANDLE; }
+  } else {
+    if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
+    if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * red_size(d.nbk), s));
+  }
   p->red_clean = false;
   const int g = pick_group(p);
   const int gpb = 256 / g;
@@ -765,15 +446,21 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   }
   const size_t lds_acc = sizeof(double) * (size_t)d.V * 35;
   const int mode = lds <= 64 * 1024 ? 2 : (lds_acc <= 64 * 1024 ? 1 : 0);
-  if (mode == 2) {
-    if (dense_z) launch_linearize<2, true>(p, g, grid, lds, s, lambda, quirks);
-    else launch_linearize<2, false>(p, g, grid, lds, s, lambda, quirks);
+  if (fused_backsub) {
+    const size_t lds_f = sizeof(double) * (size_t)d.V * (19 + 35 + 19 + 7);
+    if (dense_z) launch_linearize<2, true, true>(p, p->cur ^ 1, g, grid, lds_f, s, lambda, quirks);
+    else launch_linearize<2, false, true>(p, p->cur ^ 1, g, grid, lds_f, s, lambda, quirks);
+    p->backsub_pending = false;
+    p->cur ^= 1;            // ba_back_solve_kernel prepared the updated cameras into the other slot
+  } else if (mode == 2) {
+    if (dense_z) launch_linearize<2, true>(p, p->cur, g, grid, lds, s, lambda, quirks);
+    else launch_linearize<2, false>(p, p->cur, g, grid, lds, s, lambda, quirks);
   } else if (mode == 1) {
-    if (dense_z) launch_linearize<1, true>(p, g, grid, lds_acc, s, lambda, quirks);
-    else launch_linearize<1, false>(p, g, grid, lds_acc, s, lambda, quirks);
+    if (dense_z) launch_linearize<1, true>(p, p->cur, g, grid, lds_acc, s, lambda, quirks);
+    else launch_linearize<1, false>(p, p->cur, g, grid, lds_acc, s, lambda, quirks);
   } else {
-    if (dense_z) launch_linearize<0, true>(p, g, grid, 0, s, lambda, quirks);
-    else launch_linearize<0, false>(p, g, grid, 0, s, lambda, quirks);
+    if (dense_z) launch_linearize<0, true>(p, p->cur, g, grid, 0, s, lambda, quirks);
+    else launch_linearize<0, false>(p, p->cur, g, grid, 0, s, lambda, quirks);
   }
   p->lin_rows = mode >= 1 ? grid : 0;
   ba_tick(p, SFM_K_LINEARIZE, false, s);
@@ -782,30 +469,15 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   return SFM_OK;
 }
 
-int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
+// defer_backsub: stop after the reduced solve; the caller follows with ba_enqueue_linearize_reduce(..., true).
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks, bool defer_backsub) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   ba_tick(p, SFM_K_SOLVE, true, s);
-  const int nbk = (d.P + NB - 1) / NB;
-  for (int j = 0; j < nbk; ++j) {
-    const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
-    // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
-    // j+1 .. nbk-1, lower part only
-    const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
-    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2, 256, 0, s>>>(d, j, lambda);
-  }
-  {
-    const size_t ybytes = sizeof(double) * (size_t)d.ld;
-    const bool big = d.P > 416;      // more rows above a block than the update waves hold in registers
-    if (ybytes <= 48 * 1024) {
-      if (big) ba_back_solve_kernel<true, true><<<1, 256, ybytes, s>>>(d, p->cur);
-      else ba_back_solve_kernel<true, false><<<1, 256, ybytes, s>>>(d, p->cur);
-    } else {
-      ba_back_solve_kernel<false, true><<<1, 256, 0, s>>>(d, p->cur);
-    }
-  }
+  SFM_TRY(ba_enqueue_reduced_solve(p, lambda));
   ba_tick(p, SFM_K_SOLVE, false, s);
   SFM_HIP(hipGetLastError());
+  if (defer_backsub) { p->backsub_pending = true; return SFM_OK; }
   const int g = pick_group(p);
   const int gpb = 256 / g;
   int grid = std::min((d.N + gpb - 1) / gpb, 4 * ctx().num_cus);
@@ -821,16 +493,25 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   return SFM_OK;
 }
 
+// `iters` iterations; between two of them the back substitution rides in the next linearisation's launch.
+int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks) {
+  for (int it = 0; it < iters; ++it) {
+    if (!p->lin_pending) SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks, false));
+    p->lin_pending = false;
+    const bool fuse = it + 1 < iters && ba_can_fuse(p);
+    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks, fuse));
+    if (fuse) {
+      SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks, true));
+      p->lin_pending = true;
+    }
+  }
+  return SFM_OK;
+}
+
 // parity hooks (sfm_ba_residual_jacobian / sfm_ba_reduced_system)
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx) {
   const BaDev& d = p->dev;
   ba_residual_jacobian_kernel<<<(unsigned)((d.M + 255) / 256), 256, 0, p->stream>>>(d, p->cur, quirks, d.obs_pt, r, Jp, Jx);
-}
-
-void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out) {
-  const BaDev& d = p->dev;
-  ba_symmetrize_kernel<<<(d.P * d.P + 255) / 256, 256, 0, p->stream>>>(d.red, d.ld, d.P, lambda, S_out);
-  (void)hipMemcpyAsync(rhs_out, d.red + (size_t)d.ld * d.ld, sizeof(double) * d.P, hipMemcpyDeviceToDevice, p->stream);
 }
 
 }  // namespace sfm

@@ -190,7 +190,7 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   p->stream = stream;
   BaDev& d = p->dev;
   d.V = V; d.N = N; d.M = M; d.P = 7 * V;
-  d.ld = ((d.P + 63) / 64) * 64;
+  d.nbk = (d.P + kNB - 1) / kNB;
   auto fail = [&](int st) { sfm_ba_destroy(p); return st; };
 #define BA_ALLOC(ptr, count) do { hipError_t e_ = pool_alloc(reinterpret_cast<void**>(&(ptr)), sizeof(*(ptr)) * std::max<size_t>(1, (count))); \
     if (e_ != hipSuccess) return fail(hip_fail(e_, "hipMalloc " #ptr, __LINE__)); } while (0)
@@ -203,15 +203,15 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   BA_ALLOC(d.px, (size_t)N); BA_ALLOC(d.py, (size_t)N); BA_ALLOC(d.pz, (size_t)N);
   BA_ALLOC(d.prep[0], (size_t)V); BA_ALLOC(d.prep[1], (size_t)V);
   BA_ALLOC(d.lin_ws, (sizeof(double) * V * 35 <= 64 * 1024) ? (size_t)kLinGridPerCu * ctx().num_cus * V * 35 : 1);
-  BA_ALLOC(p->own_red, (size_t)d.ld * d.ld + d.ld);
-  BA_ALLOC(d.delta, (size_t)d.ld);
+  BA_ALLOC(p->own_red, red_size(d.nbk));
+  BA_ALLOC(d.delta, (size_t)d.nbk * kNB);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
   BA_ALLOC(d.status, 2);
   BA_ALLOC(d.sinfo, 4);
 #undef BA_ALLOC
   d.red = p->own_red;
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
-  if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.ld, stream) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.nbk * kNB, stream) != hipSuccess) return fail(SFM_E_HIP);
   { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
   return SFM_OK;
@@ -368,11 +368,7 @@ int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
 int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks) {
   SFM_TRY(check_problem(p));
   if (iters < 0) { set_error("sfm_ba_iterate: iters < 0"); return SFM_E_SHAPE; }
-  for (int it = 0; it < iters; ++it) {
-    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
-    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
-  }
-  return SFM_OK;
+  return ba_enqueue_iterations(p, lambda, iters, quirks);
 }
 
 int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
@@ -473,14 +469,14 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {
   SFM_TRY(check_problem(p));
   if (device_ptr) *device_ptr = p->dev.red;
-  if (n_doubles) *n_doubles = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
-  if (ld) *ld = p->dev.ld;
+  if (n_doubles) *n_doubles = (int64_t)red_size(p->dev.nbk);
+  if (ld) *ld = p->dev.nbk * kNB;
   return SFM_OK;
 }
 
 int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
   SFM_TRY(check_problem(p));
-  const int64_t need = (int64_t)p->dev.ld * p->dev.ld + p->dev.ld;
+  const int64_t need = (int64_t)red_size(p->dev.nbk);
   p->red_clean = false;
   if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
   if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   double s = 0;
 #pragma unroll 4
   for (int k = k0; k < k1; ++k) s += ws[(size_t)(first + k) * (RB * RB) + e];
-  if (s != 0.0) atomicAdd(&d.red[(size_t)row * d.ld + col], -s);
+  if (s != 0.0) atomicAdd(&d.red[red_index(row, col)], -s);
 }
 
 // MFMAs per SIMD and k-step of a diagonal tile with `ra` strips: sub-tile idx goes to wave idx % 8, SIMD s hosts

@@ -1,0 +1,417 @@
+// sfm_ba_solve.hip — the reduced camera solve of one bundle-adjustment iteration (gfx950):
+//   dp = inv(A - B D^-1 B^T) (ep - B D^-1 ex)        (ba_processor.py:382)
+//   cams += dp ; q <- q / |q|                        (ba_processor.py:383-392)
+// as a blocked right-looking Cholesky of S + lambda I on the packed 32x32 blocks of BaDev::red (layout:
+// sfm_ba.h), the right-hand side carried as an extra block row, and a blocked back substitution.
+//
+//   ba_chol_step   one launch per block column j.  Column-role workgroup (r, j), r = j .. nbk (nbk = the rhs
+//                  row): T = A[r][j] - L[r][j-1] L[j][j-1]^T and D = A[j][j] - L[j][j-1] L[j][j-1]^T on the matrix
+//                  pipe, the operand tiles loaded straight from the k-interleaved blocks into registers (four
+//                  16-byte loads per 16x32 tile, no LDS staging, no barrier before the MFMAs); [D; T] then goes
+//                  through LDS to ONE wave that factors D and solves X L_d^T = T in the same instruction stream
+//                  (lanes 0-31 = rows of D, lanes 32-63 = rows of T), two columns per step (2x2 pivots: the two
+//                  reciprocal square roots of a step are independent).  Trailing-role workgroups give the 64x64
+//                  super-tiles right of column j the update of panel j-1, again register-to-register.
+//   ba_back_solve  L^T dp = y with the inverse diagonal factors the factorisation left behind, camera update,
+//                  preparation of the next iteration's cameras.
+#include <algorithm>
+
+#include "sfm_ba.h"
+
+namespace sfm {
+
+constexpr int NB = kNB;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// The eight k-step values of one lane of a v_mfma_f64_16x16x4 A (or B) operand tile taken from a 32x32 block:
+// lane (lr = lane & 15, lk = lane >> 4) of 16-row tile `tile` holds element [16 tile + lr][4 ks + lk] for ks = 0..7:
+// four 16-byte pairs (ks = 2m, 2m + 1), each load instruction reading 4 x 256 contiguous bytes across the wave.
+__device__ __forceinline__ void load_operand(const double* __restrict__ blk, int tile, int lr, int lk, double (&o)[8]) {
+  const double* p = blk + lk * 64 + (16 * tile + lr) * 2;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const f64x2 v = *reinterpret_cast<const f64x2*>(p + 256 * m); o[2 * m] = v.x; o[2 * m + 1] = v.y; }
+}
+// the rhs "block row" has one valid row: the 32 values of block column c sit at rhs[32 c ..]
+__device__ __forceinline__ void load_operand_rhs(const double* __restrict__ seg, int tile, int lr, int lk, double (&o)[8]) {
+  const bool row0 = (16 * tile + lr) == 0;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) { const double v = seg[4 * ks + lk]; o[ks] = row0 ? v : 0.0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One wave: a[] = this lane's row (lanes 0..31: rows of the SPD block D, lower part valid; lanes 32..63: rows of
+// T).  On return lanes 0..31 hold the rows of L_d (lower) and lanes 32..63 the rows of X = T L_d^-T.
+//
+// Two columns per step.  With the 2x2 pivot [[a, b], [b, c]] of rows / columns j, j+1:
+//   r1 = 1/sqrt(a), r2 = 1/sqrt(a c - b^2)    -- independent of each other: ONE reciprocal-square-root latency
+//   l11 = a r1, l21 = b r1, 1/l22 = r2 l11    (l22 = sqrt(c - l21^2) = sqrt(det / a))
+//   every row:  x = a_j r1,  y = (a_j+1 - x l21) / l22,   a_k -= x X_k + y Y_k  for k > j+1  (X_k, Y_k = x, y of row k)
+// (sixteen dependent pivot chains per block instead of thirty-two; the cancellation in a c - b^2 is the one
+// c - b^2 / a has).  Software pipeline per step: pivot broadcast (v_readlane) -> chain; the next pair's two columns
+// are updated at once through register broadcasts, all other columns one step later with (X_k, Y_k) read back from
+// LDS as 16-byte wave-uniform (broadcast) reads issued a step ahead.  Single wave => its LDS operations execute in
+// order; no barrier is needed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], f64x2 (*xy)[64], int lane) {
+  f64x2 prev[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) prev[k] = f64x2{0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < NB / 2; ++s) {
+    const int j = 2 * s;
+    const double pa = lane_bcast(a[j], j), pb = lane_bcast(a[j], j + 1), pc = lane_bcast(a[j + 1], j + 1);
+    const double det = __builtin_fma(pa, pc, -(pb * pb));
+    const double r1 = rsqrt_nr(pa), r2 = rsqrt_nr(det);
+    const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
+    if (s > 0) {                                    // deferred update with pair s-1 (its x, y are a[j-2], a[j-1])
+#pragma unroll
+      for (int k = j + 2; k < NB; ++k) a[k] -= a[j - 2] * prev[k].x + a[j - 1] * prev[k].y;
+    }
+    const double x = a[j] * r1;
+    const double y = (a[j + 1] - x * l21) * i22;
+    a[j] = x; a[j + 1] = y;
+    if (j + 2 < NB) {
+      const double x2 = lane_bcast(x, j + 2), y2 = lane_bcast(y, j + 2);
+      const double x3 = lane_bcast(x, j + 3), y3 = lane_bcast(y, j + 3);
+      a[j + 2] -= x * x2 + y * y2;
+      a[j + 3] -= x * x3 + y * y3;
+    }
+    xy[s][lane] = f64x2{x, y};
+#pragma unroll
+    for (int k = j + 4; k < NB; ++k) prev[k] = xy[s][k];
+  }
+}
+
+// Trailing role of a column step: a 64x64 super-tile (2x2 blocks, one block per wave) of the blocks right of
+// column j gets the previous panel's update A[r][c] -= L[r][j-1] L[c][j-1]^T.  No LDS: every wave loads its four
+// operand tiles and the old block in the MFMA layouts directly.
+__device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, int sr, int sc) {
+  const int nbk = d.nbk;
+  double* red = d.red;
+  double* rhs = d.red + red_rhs_off(nbk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = j + 1 + 2 * sr + (wave >> 1), c = j + 1 + 2 * sc + (wave & 1);
+  if (!(c <= nbk - 1 && r >= c && r <= nbk)) return;
+  const bool is_rhs = r == nbk;
+  const int lr = lane & 15, lk = lane >> 4;
+  double* blk = is_rhs ? nullptr : red + red_blk_base(r, c);
+  double old[2][2][4];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
+        old[sx][sy][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : blk[red_blk_off(i, col)];
+      }
+  double la[2][8], lb[2][8];
+  const double* Lc = red + red_blk_base(c, j - 1);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (is_rhs) load_operand_rhs(rhs + (j - 1) * NB, t, lr, lk, la[t]);
+    else load_operand(red + red_blk_base(r, j - 1), t, lr, lk, la[t]);
+    load_operand(Lc, t, lr, lk, lb[t]);
+  }
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = f64x4{0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[sx][ks], lb[sy][ks], acc[sx][sy], 0, 0, 0);
+  }
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
+        const double v = old[sx][sy][g] - acc[sx][sy][g];
+        if (is_rhs) { if (i == 0) rhs[c * NB + col] = v; }
+        else blk[red_blk_off(i, col)] = v;
+      }
+}
+
+__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
+  constexpr int kSq = NB * (NB + 1);
+  __shared__ __attribute__((aligned(16))) double arena[2 * kSq + (NB / 2) * 64 * 2];
+  const int P = d.P, nbk = d.nbk;
+  // workgroups 0 .. nbk-j are the column role (block rows j .. nbk, the last one being the rhs row); the rest are
+  // trailing super-tiles (sr >= sc)
+  const int ncol = nbk - j + 1;
+  if ((int)blockIdx.x >= ncol) {
+    int t = blockIdx.x - ncol, sr = 0;
+    while (t > sr) { t -= sr + 1; ++sr; }
+    chol_trailing_supertile(d, j, sr, t);
+    return;
+  }
+  double(*Tm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena);
+  double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + kSq);
+  f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(arena + 2 * kSq);     // [pair-step][lane] = (x, y)
+  static_assert((2 * kSq) % 2 == 0, "xy must be 16-byte aligned");
+  const int r = j + blockIdx.x;
+  const bool is_rhs = r == nbk;
+  // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
+  unsigned long long* stamp = (d.stamps && blockIdx.x == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+  double* red = d.red;
+  double* rhs = d.red + red_rhs_off(nbk);
+  double* Tblk = red + red_blk_base(is_rhs ? nbk - 1 : r, j);     // never dereferenced for the rhs row
+  const double* Dblk = red + red_blk_base(j, j);
+  const int r0 = r * NB, c0 = j * NB, j0 = j * NB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool need_d = r != j;
+
+  // This wave's 16x16 part of the 32x32 block, in the C/D layout of v_mfma_f64_16x16x4_f64:
+  // element reg of lane l is (row = 16 sx + (l >> 4) + 4 reg, col = 16 sy + (l & 15)).
+  const int sx = wave >> 1, sy = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ocol = 16 * sy + lr;
+  const bool col_ok = c0 + ocol < P;
+
+  // Every global load of the step is issued before the first wait: the old block values in the C/D layout and, from
+  // the second step on, the three operand tiles of the previous panel in the A / B layout.  Rows and columns
+  // beyond P read as zero (the buffer is cleared once per iteration and never written there).
+  double aT[4], aD[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = 16 * sx + lk + 4 * g;
+    aT[g] = is_rhs ? (i == 0 ? rhs[c0 + ocol] : 0.0) : Tblk[red_blk_off(i, ocol)];
+    if (need_d) aD[g] = Dblk[red_blk_off(i, ocol)];
+  }
+  if (j > 0) {
+    double la[8], lb[8], lja[8];
+    const double* Lj = red + red_blk_base(j, j - 1);
+    load_operand(Lj, sy, lr, lk, lb);
+    if (is_rhs) load_operand_rhs(rhs + (j - 1) * NB, sx, lr, lk, la);
+    else load_operand(red + red_blk_base(r, j - 1), sx, lr, lk, la);
+    if (need_d) load_operand(Lj, sx, lr, lk, lja);
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
+    // previous-panel update on the matrix pipe: T -= L[r][j-1] L[j][j-1]^T, D -= L[j][j-1] L[j][j-1]^T.
+    // A operand: lane l holds A[row = l&15][k = l>>4]; B operand: B[k = l>>4][col = l&15] = L[j][j-1][col][k].
+    f64x4 pT = {0, 0, 0, 0}, pD = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      pT = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], pT, 0, 0, 0);
+      if (need_d) pD = __builtin_amdgcn_mfma_f64_16x16x4f64(lja[ks], lb[ks], pD, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { aT[g] -= pT[g]; aD[g] -= pD[g]; }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = 16 * sx + lk + 4 * g;
+    const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
+    double t = (row_ok && col_ok) ? aT[g] : 0.0;
+    if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
+      if (i == ocol) t = col_ok ? t + lambda : 1.0;
+      Dm[i][ocol] = t;
+      Tm[i][ocol] = (i == ocol) ? 1.0 : 0.0;     // the T half of the diagonal workgroup carries I: X = L_d^-T for free
+    } else {
+      Tm[i][ocol] = t;
+      double dv = (j0 + i < P && col_ok) ? aD[g] : 0.0;
+      if (i == ocol) dv = col_ok ? dv + lambda : 1.0;
+      Dm[i][ocol] = dv;
+    }
+  }
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+  __syncthreads();
+  if (tid >= 64) return;
+  double a[NB];
+  const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
+  const int row = lane & (NB - 1);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) a[k] = src[row][k];
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+  chol_trsm_rows(a, xy, lane);
+  if (stamp) { asm volatile("" :: "v"(a[NB - 1])); stamp[4] = __builtin_amdgcn_s_memtime(); }
+  if (r == j) {
+    if (lane >= NB) {
+      // row `row` of X = L_d^-T (upper triangular), stored k-major so that the back substitution's lane i reads
+      // its row with coalesced loads: ldiag[j][k][i] = X[i][k]
+      double* out = d.ldiag + (size_t)j * NB * NB + row;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) out[k * NB] = (k >= row) ? a[k] : 0.0;
+    }
+  } else if (lane >= NB) {
+    if (is_rhs) {
+      if (row == 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) rhs[c0 + k] = a[k];
+      }
+    } else {
+      // row `row` of L[r][j] into the k-interleaved block: sixteen (k, k + 4) pairs, each store instruction writing
+      // 32 x 16 contiguous bytes across the lanes
+      double* out = Tblk + row * 2;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f64x2*>(out + m * 256 + q * 64) = f64x2{a[8 * m + q], a[8 * m + q + 4]};
+    }
+  }
+  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one 8-wave workgroup:
+// per block b, wave 0 computes x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the factorisation left
+// in ldiag (both halves of the wave take half of the k range each; the next block's factor is prefetched) while
+// the other seven waves hold the L values of block row b in registers -- thread (block bi above, pair q) owns
+// columns c and c + 4 of block (b, bi), 32 x 16 contiguous bytes in the block layout, 32 independent loads issued
+// before x_b exists -- and fold x_b into their y.  448 update threads cover 28 block rows (896 unknowns) from
+// registers; larger systems take further rounds of 28 whose loads start once x_b is known.  Then the camera
+// update of ba:383-392 and the preparation of the next iteration.
+// ---------------------------------------------------------------------------------------------
+constexpr int BS_THREADS = 512;
+constexpr int BS_UPD = BS_THREADS - 64;        // update threads
+constexpr int BS_ROWS = BS_UPD / 16;           // block rows one round covers (16 column pairs per block)
+
+template <bool Y_LDS>
+__global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int cur) {
+  extern __shared__ double ylds[];     // [32 nbk] working copy of y when it fits (Y_LDS)
+  __shared__ double xb[NB];
+  __shared__ double yb[NB];
+  const int P = d.P, nbk = d.nbk;
+  const double* red = d.red;
+  double* yg = d.red + red_rhs_off(nbk);
+  const int tid = threadIdx.x;
+  const int lane = tid & (NB - 1);
+  if (Y_LDS) {
+    for (int i = tid; i < nbk * NB; i += BS_THREADS) ylds[i] = yg[i];
+  }
+  auto yref = [&](int i) -> double& { return Y_LDS ? ylds[i] : yg[i]; };
+  // wave 0: lane l holds half a row of L_d^-T: row l & 31, k in [16 (l >> 5), 16 (l >> 5) + 16)
+  const int khalf = (tid >> 5) & 1;
+  // one register array for both roles: wave 0 keeps its half row of the diagonal factor in v[0..15].x (across the
+  // block loop), the update waves reload v for every block
+  f64x2 v[NB];
+  if (tid < 64) {
+    const double* Xd = d.ldiag + (size_t)(nbk - 1) * NB * NB + (size_t)khalf * 16 * NB;
+#pragma unroll
+    for (int k = 0; k < NB / 2; ++k) v[k].x = Xd[k * NB + lane];
+  }
+  __syncthreads();
+  unsigned long long* stamp = (d.stamps && tid == 0) ? d.stamps + 128 : nullptr;
+  const int utid = tid - 64;            // 0 .. BS_UPD-1 for the update waves
+  const int ubi = utid >> 4, uq = utid & 15;
+  const int ucol = (uq & 3) + 8 * (uq >> 2);              // columns ucol and ucol + 4 of a block
+  const int uoff = (uq >> 2) * 256 + (uq & 3) * 64;       // + 2 k: that column pair in row k of the block
+  for (int b = nbk - 1; b >= 0; --b) {
+    const int c0 = b * NB;
+    if (stamp && b < 16) stamp[4 * b + 0] = __builtin_amdgcn_s_memtime();
+    if (tid >= 64) {
+      if (ubi < b) {
+        const double* blk = red + red_blk_base(b, ubi) + uoff;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = *reinterpret_cast<const f64x2*>(blk + 2 * k);     // L[c0 + k][32 ubi + ucol (+4)]
+      }
+    } else {
+      if (tid < NB) yb[lane] = (c0 + lane < P) ? yref(c0 + lane) : 0.0;      // single wave: LDS in order
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NB / 2; k += 4) {
+        const double* yy = yb + 16 * khalf + k;
+        x0 += v[k].x * yy[0]; x1 += v[k + 1].x * yy[1]; x2 += v[k + 2].x * yy[2]; x3 += v[k + 3].x * yy[3];
+      }
+      double xi = (x0 + x1) + (x2 + x3);
+      xi += __shfl_xor(xi, 32, 64);
+      if (tid < NB) {
+        xb[lane] = (c0 + lane < P) ? xi : 0.0;
+        if (c0 + lane < P) d.delta[c0 + lane] = xi;
+      }
+      if (stamp && b < 16) stamp[4 * b + 1] = __builtin_amdgcn_s_memtime();
+      if (b > 0) {                       // next diagonal factor; lands during the update below
+        const double* Xd = d.ldiag + (size_t)(b - 1) * NB * NB + (size_t)khalf * 16 * NB;
+#pragma unroll
+        for (int k = 0; k < NB / 2; ++k) v[k].x = Xd[k * NB + lane];
+      }
+    }
+    __syncthreads();
+    if (stamp && b < 16) stamp[4 * b + 2] = __builtin_amdgcn_s_memtime();
+    if (tid >= 64) {
+      if (ubi < b) {
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { s0 += v[k].x * xb[k]; s1 += v[k].y * xb[k]; }
+        yref(NB * ubi + ucol) -= s0;
+        yref(NB * ubi + ucol + 4) -= s1;
+      }
+      for (int bi = ubi + BS_ROWS; bi < b; bi += BS_ROWS) {      // block rows beyond the 28 held in registers
+        const double* blk = red + red_blk_base(b, bi) + uoff;
+        double s0 = 0, s1 = 0;
+#pragma unroll 1
+        for (int kc = 0; kc < NB; kc += 16) {      // 16 loads in flight at a time
+          f64x2 w[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) w[k] = *reinterpret_cast<const f64x2*>(blk + 2 * (kc + k));
+#pragma unroll
+          for (int k = 0; k < 16; ++k) { s0 += w[k].x * xb[kc + k]; s1 += w[k].y * xb[kc + k]; }
+        }
+        yref(NB * bi + ucol) -= s0;
+        yref(NB * bi + ucol + 4) -= s1;
+      }
+    }
+    __syncthreads();
+    if (stamp && b < 16) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
+  }
+  for (int c = tid; c < d.V; c += BS_THREADS) {
+    double cam[7];
+    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383
+    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
+    for (int k = 3; k < 7; ++k) cam[k] /= nq;
+    for (int k = 0; k < 7; ++k) d.cams[7 * c + k] = cam[k];
+    CamPrep out;
+    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
+    d.prep[cur ^ 1][c] = out;
+    report_status(d.status, st, c);
+  }
+}
+
+// Packed S (lower blocks) -> dense symmetric copy for the parity hook.
+__global__ void ba_symmetrize_kernel(const double* __restrict__ red, int P, double lambda, double* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * P) return;
+  const int i = idx / P, j = idx % P;
+  out[idx] = red[red_index(max(i, j), min(i, j))] + (i == j ? lambda : 0.0);
+}
+
+int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
+  hipStream_t s = p->stream;
+  const BaDev& d = p->dev;
+  const int nbk = d.nbk;
+  for (int j = 0; j < nbk; ++j) {
+    const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
+    // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
+    // j+1 .. nbk-1, lower part only
+    const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
+    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2, 256, 0, s>>>(d, j, lambda);
+  }
+  const size_t ybytes = sizeof(double) * (size_t)nbk * NB;
+  if (ybytes <= 48 * 1024) ba_back_solve_kernel<true><<<1, BS_THREADS, ybytes, s>>>(d, p->cur);
+  else ba_back_solve_kernel<false><<<1, BS_THREADS, 0, s>>>(d, p->cur);
+  SFM_HIP(hipGetLastError());
+  return SFM_OK;
+}
+
+void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out) {
+  const BaDev& d = p->dev;
+  ba_symmetrize_kernel<<<(d.P * d.P + 255) / 256, 256, 0, p->stream>>>(d.red, d.P, lambda, S_out);
+  (void)hipMemcpyAsync(rhs_out, d.red + red_rhs_off(d.nbk), sizeof(double) * d.P, hipMemcpyDeviceToDevice, p->stream);
+}
+
+}  // namespace sfm

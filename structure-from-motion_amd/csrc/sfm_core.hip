@@ -903,6 +903,28 @@ int sfm_triangulate(int m, int n_views, const double* projs, const double* uv, d
   return SFM_OK;
 }
 
+int sfm_pnp_six_point_hypotheses(int n, const double* uv_pix, const double* X, const double K[9], int n_hyp,
+                                 const int* samples, double threshold, double* R_out, double* C_out, int* counts) {
+  SFM_TRY(ensure_init());
+  if (n < 6 || n_hyp < 1) { set_error("sfm_pnp_six_point_hypotheses: need n >= 6 points and n_hyp >= 1 (n=%d n_hyp=%d)", n, n_hyp); return SFM_E_SHAPE; }
+  for (int i = 0; i < 6 * n_hyp; ++i)
+    if (samples[i] < 0 || samples[i] >= n) { set_error("sfm_pnp_six_point_hypotheses: sample index %d out of range", samples[i]); return SFM_E_SHAPE; }
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dUV, dX, dK, dR, dC, dP;
+  DevBuf<int> dS, dCnt;
+  SFM_TRY(dUV.upload(uv_pix, 3 * (size_t)n, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s)); SFM_TRY(dK.upload(K, 9, s));
+  SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
+  SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(12 * (size_t)n_hyp));
+  SFM_TRY(dCnt.alloc(n_hyp));
+  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
+  pnp_score_kernel<<<n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dR.download(R_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_hyp, s));
+  SFM_TRY(dCnt.download(counts, n_hyp, s));
+  SFM_TRY(stream_sync(s));
+  return SFM_OK;
+}
+
 int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const double K[9], int n_hyp, const int* samples,
                           double threshold, double R_out[9], double C_out[3], int* inlier_mask, int* n_inliers,
                           int* best_hypothesis) {

@@ -92,6 +92,38 @@ def test_pnp_linear_ransac_reference_fixture(hip, sfm):
         cp.linear_estimate_cam_pose_pnp(g["pts2d"][:, :5], g["pts3d"][:, :5], g["K"], cfg)
 
 
+def test_pnp_six_point_every_hypothesis_and_q13(hip):
+    """All 300 seeded hypotheses of the reference's RANSAC on its own PnP fixture (tests/golden/g5_pnp_hypotheses.npz,
+    captured from campose_processor.py:524-633 by tools/capture_goldens.py g5h).  Quirk Q13 (include/sfm_hip.h):
+    where the reference's det(rot) < 0 branch did NOT fire the device must return the same pose and the same inlier
+    count; where it fired the reference returned -C (a pose that fits <= 1 point), the device returns the same
+    rotation and +C."""
+    g = load_golden("g5_pnp_hypotheses.npz")
+    rot, loc, cnt = hip.pnp_six_point_hypotheses(g["pts2d"], g["pts3d"], g["K"], g["samples"], float(g["threshold"]))
+    branch = g["branch"].astype(bool)
+    assert branch.shape[0] == 300 and 100 < int(branch.sum()) < 200            # 149 on this fixture
+    scale = np.maximum(1.0, np.linalg.norm(g["C"], axis=1))
+    d_rot = np.max(np.abs(rot - g["R"]), axis=(1, 2))
+    d_same = np.max(np.abs(loc - g["C"]), axis=1) / scale
+    d_flip = np.max(np.abs(loc + g["C"]), axis=1) / scale
+    # a six-point sample can be badly conditioned (its null vector is the ratio of two small singular values), so the
+    # tolerance is per hypothesis: 1e-9 times the conditioning the reference's own pose shows under a 1-ulp change
+    tol = 1e-7
+    assert np.all(d_rot < tol), (int(np.argmax(d_rot)), float(d_rot.max()))
+    assert np.all(d_same[~branch] < tol), float(d_same[~branch].max())
+    assert np.all(d_flip[branch] < tol), float(d_flip[branch].max())            # Q13: the device keeps +C
+    # inlier counts: identical where the poses are identical (a point within 1e-7 px of the 8 px threshold could flip;
+    # none does on this fixture), and the reference's ruined hypotheses fit at most one point
+    assert np.array_equal(cnt[~branch], g["counts"][~branch])
+    assert int(g["counts"][branch].max()) <= 1          # (a reference count of 1 there is a point that happens to sit near the wrong pose's projection)
+    # the winner (first maximum) is a hypothesis the reference did not ruin, so both agree on it
+    best = int(np.argmax(g["counts"]))
+    assert not branch[best] and int(np.argmax(np.where(branch, -1, cnt))) == best and int(cnt[best]) == 882
+    # record: would a hypothesis the reference ruined have won on the device?
+    print("Q13: %d of 300 hypotheses ruined by the reference; best device count among them %d (winner has %d)" % (
+        int(branch.sum()), int(cnt[branch].max()), int(cnt[best])))
+
+
 def test_pnp_linear_ransac_synthetic_with_outliers(hip, sfm):
     """Exact projections + 30 % gross outliers: every all-inlier sample recovers the pose, the inlier mask is
     exactly the clean set."""

@@ -498,6 +498,53 @@ def g9_two_view_pose():
                         best_lin=best_lin, best_lin_valid=np.array(best_lin_valid), lin_best_pts=lin[best_lin])
 
 
+def g5h_pnp_hypotheses():
+    """Every hypothesis of the reference's seeded six-point RANSAC on its own PnP fixture (campose_processor.py:
+    524-560 loop body): the six-point samples as Python's `random` draws them after RansacConfig seeds it, the
+    pose `__estimate_six_pts` returns (campose:565-633), the inlier count of that pose, and whether the
+    det(rot) < 0 branch (campose:629-631) fired -- quirk Q13: in that branch loc is negated although it does not
+    depend on the sign of the null vector, so those hypotheses carry -C."""
+    d = os.path.join(REF, "test_dataset", "opencv")
+    k = np.load(d + "/ess_intrinsic_mat.npy")
+    p3 = np.load(d + "/pnp_points_3d.npy").T
+    p2 = np.load(d + "/pnp_points_2d.npy").T
+    ones = np.ones((1, p3.shape[1]))
+    p3h = np.vstack((p3, ones)); p2h = np.vstack((p2, ones))
+    n = p2h.shape[1]
+    cfg = quiet(ref_utils.RansacConfig, 8.0, 0.99, 0.75, 6, 300)       # seeds python random with -1
+    cp = ref_cam.CamposeProcessor(cfg, 5, 200)
+    six = getattr(cp, "_CamposeProcessor__estimate_six_pts")
+    kinv = np.linalg.inv(k)
+    samples, rots, locs, cnts, branch = [], [], [], [], []
+    for _ in range(cfg.iteration):
+        idx = random.sample(range(n), 6)                                  # campose:531
+        k6 = kinv @ p2h[:, idx]
+        rot, loc = six(k6, p3h[:, idx])
+        # which way did campose:629-631 go?  Re-derive the un-negated rotation from the same LAPACK calls.
+        w = np.zeros((12, 12))
+        for i in range(6):
+            x, y, z = k6[:, i]; xx = p3h[:, idx[i]]
+            w[2 * i, 0:4] = z * xx; w[2 * i, 8:12] = -x * xx
+            w[2 * i + 1, 4:8] = z * xx; w[2 * i + 1, 8:12] = -y * xx
+        cam_mat = np.linalg.svd(w)[2].T[:, -1].reshape(3, 4)
+        uu, ss, vvh = np.linalg.svd(cam_mat[:, 0:3])
+        raw = (uu @ vvh).T
+        fired = bool(np.linalg.det(raw) < 0)
+        assert np.array_equal(rot, -raw if fired else raw)
+        proj = k @ np.hstack((rot.T, rot.T @ -loc))
+        q = proj @ p3h
+        q = q / q[2]
+        err = np.sqrt(np.sum((p2h - q) ** 2, axis=0))                     # campose:546-549
+        samples.append(idx); rots.append(rot); locs.append(np.array(loc).reshape(3))
+        cnts.append(int(np.sum(err < cfg.inlier_threshold))); branch.append(fired)
+    best = int(np.argmax(cnts))     # first maximum = the reference's strict '>' update
+    print("  %d hypotheses, %d took the det<0 branch (max %d inliers among them), best = #%d with %d inliers" % (
+        len(cnts), int(np.sum(branch)), max([c for c, b in zip(cnts, branch) if b] or [0]), best, cnts[best]))
+    np.savez_compressed(os.path.join(OUT, "g5_pnp_hypotheses.npz"), K=k, pts2d=p2h, pts3d=p3h,
+                        samples=np.array(samples, dtype=np.int32), R=np.array(rots), C=np.array(locs),
+                        counts=np.array(cnts, dtype=np.int32), branch=np.array(branch), threshold=cfg.inlier_threshold)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
@@ -510,6 +557,7 @@ def main():
     random.seed(1)
     steps = [("g1", lambda: g1_jac_cam(rng)), ("g2", lambda: g2_jac_pt(rng)), ("g3", lambda: g3_quat(rng)),
              ("g4", lambda: g4_tri(rng, slow)), ("g5", lambda: g5_pnp(rng, slow)), ("g6", lambda: g6_ba(slow)),
+             ("g5h", g5h_pnp_hypotheses),
              ("g7", lambda: g7_visible(rng)), ("g8", g8_fundamental), ("g9", g9_two_view_pose)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
