@@ -59,6 +59,10 @@ extern "C" {
 
 #define SFM_OPT_SCHUR        1
 #define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, results unchanged) */
+#define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
+                                 * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
+                                 * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
+                                 * and V <= 234; slower (C3: see DESIGN.md). */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
@@ -210,6 +214,12 @@ int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams /*[V][7]*/);
 int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts /*[3][count]*/);
 /* Enqueue `iters` damped Gauss-Newton iterations (ba_processor.py:297-406) on the library stream. */
 int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks);
+/* Per-iteration statistics without a state download (the `stats` of SURVEY.md section 8(b)): cost[i] = sum over this
+ * problem's observations of |b - f|^2 in normalised image coordinates (the quantity ba_processor.py:376 minimises)
+ * at the linearisation point of iteration i, for the iterations run since the state was last uploaded (set_state /
+ * set_cameras / set_points / append start a new history; at most 256 iterations are kept).  sqrt(cost / M) is the RMS
+ * residual; in a sharded run every rank reports its own observations.  Synchronises. */
+int sfm_ba_get_stats(sfm_ba_problem* p, double* cost /*[max_iters]*/, int max_iters, int* n_iters);
 /* Synchronise, copy the state back, and report the first device-side failure (bad rotation ...). */
 int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
 /* Grow a resident problem in place — the incremental pipeline registers a view, triangulates new points and

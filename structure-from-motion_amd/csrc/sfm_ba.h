@@ -30,6 +30,7 @@ constexpr int kLinGridPerCu = 3; // ba_linearize workgroups per CU (132 VGPRs ->
 // as sixteen such pairs, coalesced across the 32 rows; columns c and c + 4 of one block row are neighbours as
 // well (what the back substitution reads).  Nothing outside sfm_ba_solve.hip sees that order.
 // ---------------------------------------------------------------------------------------------
+constexpr int kStatSlots = 256;   // iterations sfm_ba_get_stats can report between two state uploads
 constexpr int kNB = 32;
 constexpr int kBlk = kNB * kNB;
 __host__ __device__ inline size_t red_blk_base(int br, int bc) { return ((size_t)br * (br + 1) / 2 + bc) * kBlk; }
@@ -71,6 +72,8 @@ struct BaDev {
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
+  double* cost = nullptr;   // [kStatSlots] sum |b - f|^2 over this problem's observations at the start of iteration i
+  int* iter_count = nullptr;  // [1] iterations completed since the state was last set (advanced by ba_back_solve)
   unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };
 
@@ -119,6 +122,7 @@ struct sfm_ba_problem {
   int schur_mode = SFM_SCHUR_AUTO;
   int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight
   int debug = 0;             // SFM_OPT_DEBUG: profiling ablations (results are wrong when set)
+  int deterministic = 0;     // SFM_OPT_DETERMINISTIC: fixed summation order everywhere (bitwise repeatable results)
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)

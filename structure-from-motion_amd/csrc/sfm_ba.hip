@@ -67,8 +67,10 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // over the observation list per iteration instead of two (ba_backsub + ba_linearize).  The kernel also clears
 // [S | rhs], which is dead once the reduced solve has run.
 // ---------------------------------------------------------------------------------------------
-template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED>
-__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
+// THREADS = 64 (one wave per workgroup) is the deterministic variant: the camera accumulators in LDS then receive
+// their ds_add_f64 from a single instruction stream, in program order.
+template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   static_assert(!FUSED || LDS_MODE == 2, "the fused kernel keeps both camera sets in LDS");
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
@@ -98,11 +100,12 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_red; i += (size_t)gridDim.x * blockDim.x) d.red[i] = 0.0;
   }
   if (stamp) stamp[sidx++] = __builtin_amdgcn_s_memtime();
-  constexpr int GPB = 256 / G;                 // point groups per block
+  constexpr int GPB = THREADS / G;             // point groups per block
   const int lane_g = threadIdx.x % G;
   const int grp = threadIdx.x / G;
   double* S = d.red;
   double* rhs = d.red + red_rhs_off(d.nbk);
+  double cost = 0.0;                           // sum |b - f|^2 of this lane's observations (sfm_ba_get_stats)
 
   for (int p0 = blockIdx.x * GPB; p0 < d.N; p0 += gridDim.x * GPB) {
     const int p = p0 + grp;
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
           zo[20] = zz[20];
         }
       }
+      cost += r[0] * r[0] + r[1] * r[1];
       // rhs_c -= W V^-1 g = Jp^T (Jx h) with h = V^-1 g: folded into the residual, e = r - Jx h
       const double e0 = r[0] - (Jx[0] * h0 + Jx[1] * h1 + Jx[2] * h2);
       const double e1 = r[1] - (Jx[3] * h0 + Jx[4] * h1 + Jx[5] * h2);
@@ -254,6 +258,10 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev d, int cur, dou
     }
   }
   if (stamp && sidx < 62) stamp[sidx++] = __builtin_amdgcn_s_memtime();
+  {
+    cost = wave_sum(cost);
+    if ((threadIdx.x & 63) == 0 && cost != 0.0) atomicAdd(&d.cost[min(*d.iter_count, kStatSlots - 1)], cost);
+  }
   if (ACC_LDS) {
     // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_schur_reduce_kernel adds
     // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
@@ -366,6 +374,16 @@ static int pick_group(const sfm_ba_problem* p) {
 template <int LDS, bool WZ, bool FUSED = false>
 static void launch_linearize(const sfm_ba_problem* p, int cur, int g, int grid, size_t lds, hipStream_t s, double lambda, int quirks) {
   const BaDev& d = p->dev;
+  if (p->deterministic) {      // one wave per workgroup (ordered LDS accumulation)
+    switch (g) {
+      case 4: ba_linearize_kernel<4, LDS, WZ, FUSED, 64><<<grid, 64, lds, s>>>(d, cur, lambda, quirks); break;
+      case 8: ba_linearize_kernel<8, LDS, WZ, FUSED, 64><<<grid, 64, lds, s>>>(d, cur, lambda, quirks); break;
+      case 16: ba_linearize_kernel<16, LDS, WZ, FUSED, 64><<<grid, 64, lds, s>>>(d, cur, lambda, quirks); break;
+      case 32: ba_linearize_kernel<32, LDS, WZ, FUSED, 64><<<grid, 64, lds, s>>>(d, cur, lambda, quirks); break;
+      default: ba_linearize_kernel<64, LDS, WZ, FUSED, 64><<<grid, 64, lds, s>>>(d, cur, lambda, quirks); break;
+    }
+    return;
+  }
   switch (g) {
     case 4: ba_linearize_kernel<4, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
     case 8: ba_linearize_kernel<8, LDS, WZ, FUSED><<<grid, 256, lds, s>>>(d, cur, lambda, quirks); break;
@@ -433,7 +451,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bo
   }
   p->red_clean = false;
   const int g = pick_group(p);
-  const int gpb = 256 / g;
+  const int gpb = (p->deterministic ? 64 : 256) / g;
   int grid = std::min((d.N + gpb - 1) / gpb, kLinGridPerCu * ctx().num_cus);
   if (grid < 1) grid = 1;
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);

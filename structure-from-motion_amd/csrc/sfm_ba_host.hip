@@ -208,12 +208,23 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
   BA_ALLOC(d.status, 2);
   BA_ALLOC(d.sinfo, 4);
+  BA_ALLOC(d.cost, kStatSlots);
+  BA_ALLOC(d.iter_count, 1);
 #undef BA_ALLOC
   d.red = p->own_red;
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.cost, 0, kStatSlots * sizeof(double), stream) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.iter_count, 0, sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.nbk * kNB, stream) != hipSuccess) return fail(SFM_E_HIP);
   { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
+  return SFM_OK;
+}
+
+// A new state starts a new cost history (sfm_ba_get_stats).
+static int ba_reset_stats(sfm_ba_problem* p) {
+  SFM_HIP(hipMemsetAsync(p->dev.cost, 0, kStatSlots * sizeof(double), p->stream));
+  SFM_HIP(hipMemsetAsync(p->dev.iter_count, 0, sizeof(int), p->stream));
   return SFM_OK;
 }
 
@@ -263,7 +274,8 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited && p->stream) (void)hipStreamSynchronize(p->stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, p->schur_ws, p->schur_blk_ptr};
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.iter_count,
+                  p->schur_ws, p->schur_blk_ptr};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -296,6 +308,14 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
     case SFM_OPT_TIMING:
       p->timing = value;   // bit k set = time kernel class k
       return SFM_OK;
+    case SFM_OPT_DETERMINISTIC:
+      if (value != 0) {
+        // needs the atomic-free dense product (Zd resident) and the LDS camera accumulators of ba_linearize
+        if (!p->schur_mfma_ok) { set_error("deterministic mode needs the dense Schur product, which does not fit this scene"); return SFM_E_SHAPE; }
+        if (sizeof(double) * (size_t)p->dev.V * 35 > 64 * 1024) { set_error("deterministic mode supports at most 234 cameras"); return SFM_E_SHAPE; }
+      }
+      p->deterministic = value != 0;
+      return SFM_OK;
     default:
       set_error("unknown option %d", option);
       return SFM_E_SHAPE;
@@ -321,6 +341,7 @@ int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams) {
   BaDev& d = p->dev;
   SFM_TRY(ba_upload(p, d.cams, cams, sizeof(double) * 7 * d.V));
   SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), p->stream));
+  SFM_TRY(ba_reset_stats(p));
   SFM_TRY(stream_sync(p->stream));
   p->prep_valid = false;
   return SFM_OK;
@@ -336,6 +357,7 @@ int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts
   SFM_TRY(ba_upload(p, d.px + first, pts, sizeof(double) * count));
   SFM_TRY(ba_upload(p, d.py + first, pts + count, sizeof(double) * count));
   SFM_TRY(ba_upload(p, d.pz + first, pts + 2 * (size_t)count, sizeof(double) * count));
+  SFM_TRY(ba_reset_stats(p));
   SFM_TRY(stream_sync(p->stream));
   return SFM_OK;
 }
@@ -350,8 +372,22 @@ int sfm_ba_set_state(sfm_ba_problem* p, const double* cams, const double* pts) {
     SFM_TRY(ba_upload(p, d.pz, pts + 2 * (size_t)d.N, sizeof(double) * d.N));
   }
   SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), p->stream));
+  SFM_TRY(ba_reset_stats(p));
   SFM_TRY(stream_sync(p->stream));
   p->prep_valid = false;
+  return SFM_OK;
+}
+
+int sfm_ba_get_stats(sfm_ba_problem* p, double* cost, int max_iters, int* n_iters) {
+  SFM_TRY(check_problem(p));
+  if (max_iters < 0 || (max_iters > 0 && cost == nullptr)) { set_error("sfm_ba_get_stats: bad output buffer"); return SFM_E_SHAPE; }
+  int done = 0;
+  SFM_HIP(hipMemcpyAsync(&done, p->dev.iter_count, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  SFM_TRY(stream_sync(p->stream));
+  const int n = std::min(std::min(done, kStatSlots), max_iters);
+  if (n > 0) SFM_HIP(hipMemcpyAsync(cost, p->dev.cost, sizeof(double) * n, hipMemcpyDeviceToHost, p->stream));
+  SFM_TRY(stream_sync(p->stream));
+  if (n_iters) *n_iters = n;
   return SFM_OK;
 }
 
@@ -448,6 +484,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   if (st != SFM_OK) { (void)hipStreamSynchronize(s); sfm_ba_destroy(q); return st; }
   // the handle keeps its identity, options, stream and counters; the old buffers leave with q
   q->schur_mode = p->schur_mode; q->debug = p->debug; q->timing = p->timing; q->quirks = p->quirks;
+  q->deterministic = p->deterministic && q->schur_mfma_ok && sizeof(double) * (size_t)q->dev.V * 35 <= 64 * 1024;
   const bool had_external_red = p->dev.red != p->own_red;
   std::swap(p->dev, q->dev);
   std::swap(p->own_red, q->own_red);

@@ -478,6 +478,45 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   if (s != 0.0) atomicAdd(&d.red[red_index(row, col)], -s);
 }
 
+// Deterministic variant (SFM_OPT_DETERMINISTIC): ONE thread owns an element of S: it sums the tile's split-K slabs
+// in chunk order, adds -- for an element of a camera's diagonal 7x7 block -- the per-workgroup camera accumulators
+// of ba_linearize in row order, and stores the result; no atomics, so the summation order is fixed.  Extra blocks
+// do the same for rhs.
+__global__ __launch_bounds__(256) void ba_schur_reduce_det_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan,
+                                                                  int tile_blocks, int lin_rows) {
+  if ((int)blockIdx.x >= tile_blocks) {
+    const int t = (blockIdx.x - tile_blocks) * 256 + threadIdx.x;      // rhs element
+    if (t >= d.P) return;
+    const int c = t / 7, i = t - 7 * c;
+    double s = 0;
+    for (int r = 0; r < lin_rows; ++r) s += d.lin_ws[(size_t)r * d.V * 35 + c * 35 + 28 + i];
+    d.red[red_rhs_off(d.nbk) + t] = s;
+    return;
+  }
+  const int ntiles = plan.n_off + plan.nblk;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ntiles * RB * RB) return;
+  const int tile = idx / (RB * RB);
+  const int e = idx - tile * (RB * RB);
+  const SchurTileRef tr = plan_tile(plan, tile);
+  const int ti = tr.ti, tj = tr.tj, first = tr.first, chunks = plan.chunks[tr.cls];
+  const int r = e / RB, c = e - r * RB;
+  if (r >= 7 * CB || c >= 7 * CB) return;
+  const int cam_r = ti * CB + r / 7, cam_c = tj * CB + c / 7;
+  if (cam_r >= d.V || cam_c >= d.V) return;
+  const int row = 7 * cam_r + r % 7, col = 7 * cam_c + c % 7;
+  if (col > row) return;
+  double s = 0;
+  for (int k = 0; k < chunks; ++k) s += ws[(size_t)(first + k) * (RB * RB) + e];
+  double u = 0;
+  if (cam_r == cam_c) {
+    const int i = r % 7, j = c % 7;
+    const int t = cam_r * 35 + i * (i + 1) / 2 + j;
+    for (int q = 0; q < lin_rows; ++q) u += d.lin_ws[(size_t)q * d.V * 35 + t];
+  }
+  d.red[red_index(row, col)] = u - s;
+}
+
 // MFMAs per SIMD and k-step of a diagonal tile with `ra` strips: sub-tile idx goes to wave idx % 8, SIMD s hosts
 // waves s and s + 4.
 static int diag_cost(int ra) {
@@ -576,6 +615,7 @@ int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
 
 bool ba_schur_uses_mfma(const sfm_ba_problem* p) {
   if (!p->schur_mfma_ok) return false;
+  if (p->deterministic) return true;        // the sparse product accumulates with unordered LDS atomics
   if (p->schur_mode == SFM_SCHUR_MFMA) return true;
   if (p->schur_mode == SFM_SCHUR_PAIRS) return false;
   const BaDev& d = p->dev;
@@ -620,7 +660,8 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const int tile_blocks = (ntiles * RB * RB + 255) / 256;
   const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
   ba_tick(p, SFM_K_REDUCE, true, s);
-  ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
+  if (p->deterministic) ba_schur_reduce_det_kernel<<<tile_blocks + (d.P + 255) / 256, 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
+  else ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
   ba_tick(p, SFM_K_REDUCE, false, s);
   SFM_HIP(hipGetLastError());
   return SFM_OK;

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
     __syncthreads();
     if (stamp && b < 16) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
   }
+  if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
   for (int c = tid; c < d.V; c += BS_THREADS) {
     double cam[7];
     for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383

@@ -10,13 +10,15 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfm_hip.so")
+# SFM_HIP_LIBRARY selects another build of the same library (tools/asan_host_check.sh points it at the
+# -fsanitize=address,undefined host build); the default is the in-tree gfx950 build next to this file.
+LIB_PATH = os.environ.get("SFM_HIP_LIBRARY") or os.path.join(_HERE, "libsfm_hip.so")
 
 OK = 0
 E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK = -1, -2, -3, -4, -5, -6, -7, -8
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
 SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA = 0, 1, 2
-OPT_SCHUR, OPT_TIMING, OPT_DEBUG = 1, 2, 3
+OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC = 1, 2, 3, 4
 K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
 INFO_SCHUR_KERNEL, INFO_UPLOAD_BYTES, INFO_N_CAMS, INFO_N_PTS, INFO_N_OBS, INFO_MAX_TRACK = 1, 2, 3, 4, 5, 6
@@ -30,7 +32,7 @@ EXPORTS = (
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
-    "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points",
+    "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points", "sfm_ba_get_stats",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
@@ -426,6 +428,14 @@ class BaProblem:
 
     def solve_update(self, lam, quirks=QUIRKS_REFERENCE):
         check(self._lib.sfm_ba_solve_update(self._h, float(lam), int(quirks)))
+
+    def get_stats(self, max_iters=256):
+        """Per-iteration cost sum |b - f|^2 (normalised image coordinates) at the start of every iteration run since
+        the state was last uploaded -- no state download needed (sfm_ba_get_stats)."""
+        out = np.empty(max_iters); n = ctypes.c_int()
+        self._lib.sfm_ba_get_stats.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _ip]
+        check(self._lib.sfm_ba_get_stats(self._h, dptr(out), int(max_iters), ctypes.byref(n)))
+        return out[:n.value].copy()
 
     def get_state(self):
         cams = np.empty((self.n_cams, 7)); pts = np.empty((3, self.n_pts))

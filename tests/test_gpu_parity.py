@@ -336,6 +336,51 @@ def test_ba_edge_cases(hip, oracle, sfm):
         hip.ba_solve(3, sc.pt_ptr, ci, uvn, sc.cams_init, sc.pts_init, 5.0, 1)
 
 
+@pytest.mark.parametrize("n_cams,mode", [(9, "pairs"), (30, "mfma"), (120, "auto")])
+def test_ba_per_iteration_cost_statistics(hip, oracle, sfm, n_cams, mode):
+    """sfm_ba_get_stats: cost[i] = sum |b - f|^2 (normalised coordinates, ba_processor.py:376) at the linearisation
+    point of iteration i, accumulated on the device -- against the oracle's residuals at the oracle's states.  Covers
+    the fused back-substitution + linearisation launch (9 / 30 cameras) and the separate launches (120 cameras: the
+    fused kernel's LDS budget is exceeded), and the history reset on a state upload."""
+    sc = sfm.scenes.make_scene(n_cams, 900, 0.4, seed=61)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    trace = []
+    oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 4, trace=trace)
+    states = [(sc.cams_init, sc.pts_init)] + trace[:3]
+    want = [float(np.sum(oracle.obs_terms_vec(c, p, sc.cam_idx, sc.pt_idx, uvn)[0] ** 2)) for c, p in states]
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, {"pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "auto": hip.SCHUR_AUTO}[mode])
+        prob.set_state(sc.cams_init, sc.pts_init)
+        assert prob.get_stats().shape == (0,)
+        prob.iterate(5.0, 3)
+        prob.iterate(5.0, 1)
+        got = prob.get_stats()
+        assert got.shape == (4,) and rel(got, np.array(want)) < 1e-10
+        assert np.all(np.diff(got) < 0)                       # the damped Gauss-Newton steps reduce the cost here
+        cams, pts = prob.get_state()
+        assert rel(cams, trace[3][0]) < TOL and rel(pts, trace[3][1]) < TOL
+        prob.set_state(sc.cams_init, sc.pts_init)             # a new state starts a new history
+        prob.iterate(5.0, 1)
+        again = prob.get_stats()
+        assert again.shape == (1,) and rel(again, np.array(want[:1])) < 1e-10
+
+
+def test_ba_fused_and_separate_launches_agree(hip, sfm):
+    """The back substitution riding in the next linearisation's launch (default) against the two separate kernels
+    (SFM_OPT_DEBUG bit 16): same arithmetic, same state."""
+    sc = sfm.scenes.make_scene(14, 1500, 0.5, seed=62)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    out = []
+    for dbg in (0, 16):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 4)
+            out.append(prob.get_state())
+    assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-13
+
+
 def test_ba_split_phases_equal_iterate(hip, sfm):
     """linearize_reduce + solve_update (the multi-GPU split) == iterate on one rank."""
     sc = sfm.scenes.make_scene(7, 500, 0.5, seed=4)
@@ -462,6 +507,29 @@ def test_ba_repeatable_and_state_reset(hip, sfm):
             runs.append(prob.get_state())
     for c, p in runs[1:]:
         assert rel(c, runs[0][0]) < 1e-13 and rel(p, runs[0][1]) < 1e-13
+
+
+@pytest.mark.parametrize("shape", [(40, 6000, 0.5), (170, 1500, 0.12)])
+def test_ba_deterministic_mode_is_bitwise_repeatable(hip, oracle, sfm, shape):
+    """SFM_OPT_DETERMINISTIC: fixed summation order (one wave per ba_linearize workgroup, atomic-free dense Schur
+    product, single-writer reduce).  Fresh problems and a re-run on the same problem give bit-identical states, and
+    the result is still the oracle's to 1e-9.  The second shape keeps only the camera accumulators in LDS."""
+    n_cams, n_pts, vis = shape
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=71)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    runs = []
+    for rep in range(2):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_DETERMINISTIC, 1)
+            assert prob.info(hip.INFO_SCHUR_KERNEL) == hip.SCHUR_MFMA
+            for _ in range(2):
+                prob.set_state(sc.cams_init, sc.pts_init)
+                prob.iterate(5.0, 4)
+                runs.append(prob.get_state())
+    for c, p in runs[1:]:
+        assert np.array_equal(c, runs[0][0]) and np.array_equal(p, runs[0][1])
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 4)
+    assert rel(runs[0][0], ocams) < TOL and rel(runs[0][1], opts) < TOL
 
 
 def test_tri_many_views_global_projection_path(hip, oracle, sfm):
