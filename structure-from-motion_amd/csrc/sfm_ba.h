@@ -73,9 +73,18 @@ struct BaDev {
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
   double* cost = nullptr;   // [kStatSlots] sum |b - f|^2 over this problem's observations at the start of iteration i
+  double* cost_ws = nullptr;  // [linearize workgroups] per-workgroup partial cost of the last linearisation
   int* iter_count = nullptr;  // [1] iterations completed since the state was last set (advanced by ba_back_solve)
   unsigned long long* stamps = nullptr;   // diagnostic shader-clock stamps (SFM_OPT_DEBUG bit 8), else null
 };
+
+// Sum of ba_linearize's per-workgroup partial costs -> cost[iteration] (one wave, fixed order).
+__device__ __forceinline__ void cost_reduce(const BaDev& d, int nrows) {
+  double s = 0;
+  for (int r = threadIdx.x; r < nrows; r += 64) s += d.cost_ws[r];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) d.cost[min(*d.iter_count, kStatSlots - 1)] = s;
+}
 
 // Slice `slice` of `nslices` of the sum over ba_linearize's per-workgroup camera accumulators (lin_ws rows)
 // for accumulator element t, added into the diagonal blocks of S (lower part) / rhs with one f64 atomic.
@@ -115,6 +124,7 @@ struct sfm_ba_problem {
   int cur = 0;               // which prep slot holds the cameras of the current state
   bool prep_valid = false;
   int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
+  int lin_grid = 0;          // workgroups of the last ba_linearize (rows of cost_ws)
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
   bool backsub_pending = false;   // the reduced solve ran, its back substitution waits for the fused launch
   bool lin_pending = false;       // inside ba_enqueue_iterations: the next iteration is already linearised

@@ -259,8 +259,18 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
   }
   if (stamp && sidx < 62) stamp[sidx++] = __builtin_amdgcn_s_memtime();
   {
+    // one partial cost per workgroup, plain store; ba_schur_reduce adds them up (3000 waves adding to ONE address
+    // with global atomics cost 18 us at C3: same-address atomics serialise at the memory side)
+    __shared__ double wcost[THREADS / 64];
     cost = wave_sum(cost);
-    if ((threadIdx.x & 63) == 0 && cost != 0.0) atomicAdd(&d.cost[min(*d.iter_count, kStatSlots - 1)], cost);
+    if ((threadIdx.x & 63) == 0) wcost[threadIdx.x >> 6] = cost;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0;
+#pragma unroll
+      for (int w = 0; w < THREADS / 64; ++w) t += wcost[w];
+      d.cost_ws[blockIdx.x] = t;
+    }
   }
   if (ACC_LDS) {
     // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_schur_reduce_kernel adds
@@ -481,6 +491,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bo
     else launch_linearize<0, false>(p, p->cur, g, grid, 0, s, lambda, quirks);
   }
   p->lin_rows = mode >= 1 ? grid : 0;
+  p->lin_grid = grid;
   ba_tick(p, SFM_K_LINEARIZE, false, s);
   SFM_HIP(hipGetLastError());
   SFM_TRY(ba_enqueue_schur(p, s));

@@ -209,6 +209,7 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   BA_ALLOC(d.status, 2);
   BA_ALLOC(d.sinfo, 4);
   BA_ALLOC(d.cost, kStatSlots);
+  BA_ALLOC(d.cost_ws, (size_t)kLinGridPerCu * ctx().num_cus);
   BA_ALLOC(d.iter_count, 1);
 #undef BA_ALLOC
   d.red = p->own_red;
@@ -274,7 +275,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (ctx().inited && p->stream) (void)hipStreamSynchronize(p->stream);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.iter_count,
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
                   p->schur_ws, p->schur_blk_ptr};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)

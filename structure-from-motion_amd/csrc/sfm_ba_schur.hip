@@ -449,7 +449,11 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, d
 // b*CB + r/7, parameter r%7.  One thread per padded tile element; blockIdx.y slices the chunk range
 // (more loads in flight), one f64 atomic per slice and element.
 __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan, int tile_blocks,
-                                                              int lin_rows) {
+                                                              int lin_rows, int lin_grid) {
+  if (blockIdx.x == gridDim.x - 1) {           // last block: the per-workgroup partial costs of ba_linearize
+    if (blockIdx.y == 0 && threadIdx.x < 64) cost_reduce(d, lin_grid);
+    return;
+  }
   if ((int)blockIdx.x >= tile_blocks) {
     // extra blocks: the camera-side sums of ba_linearize (U_c, rhs_c), 12 x gridDim.y slices
     const int cam_blocks = (d.V * 35 + 255) / 256;
@@ -483,7 +487,11 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
 // of ba_linearize in row order, and stores the result; no atomics, so the summation order is fixed.  Extra blocks
 // do the same for rhs.
 __global__ __launch_bounds__(256) void ba_schur_reduce_det_kernel(BaDev d, const double* __restrict__ ws, SchurPlan plan,
-                                                                  int tile_blocks, int lin_rows) {
+                                                                  int tile_blocks, int lin_rows, int lin_grid) {
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < 64) cost_reduce(d, lin_grid);
+    return;
+  }
   if ((int)blockIdx.x >= tile_blocks) {
     const int t = (blockIdx.x - tile_blocks) * 256 + threadIdx.x;      // rhs element
     if (t >= d.P) return;
@@ -660,8 +668,8 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const int tile_blocks = (ntiles * RB * RB + 255) / 256;
   const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
   ba_tick(p, SFM_K_REDUCE, true, s);
-  if (p->deterministic) ba_schur_reduce_det_kernel<<<tile_blocks + (d.P + 255) / 256, 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
-  else ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows);
+  if (p->deterministic) ba_schur_reduce_det_kernel<<<tile_blocks + (d.P + 255) / 256 + 1, 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows, p->lin_grid);
+  else ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks + 1, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows, p->lin_grid);
   ba_tick(p, SFM_K_REDUCE, false, s);
   SFM_HIP(hipGetLastError());
   return SFM_OK;
