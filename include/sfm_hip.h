@@ -58,7 +58,7 @@ extern "C" {
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, results unchanged) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 32 = one-wave elimination in ba_chol_step: results unchanged) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
@@ -250,6 +250,11 @@ int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n);
  * sfm_ba_iterate == these two back to back on one rank. */
 int sfm_ba_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
 int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+/* sfm_ba_solve_update may leave the back substitution of the points (ba_processor.py:405-406) to the next
+ * sfm_ba_linearize_reduce, whose launch then does both in one pass over the observations.  Every entry point that
+ * reads or replaces the state completes it first; a loop that only times linearize_reduce / solve_update calls ends
+ * with sfm_ba_flush so that its last iteration is complete as well.  Enqueues only. */
+int sfm_ba_flush(sfm_ba_problem* p);
 /* DEVICE pointer + element count of the contiguous reduced buffer (doubles). */
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld);
 /* Bind an externally owned DEVICE buffer (e.g. a torch tensor) as the reduced buffer. */

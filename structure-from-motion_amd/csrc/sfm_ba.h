@@ -70,6 +70,7 @@ struct BaDev {
   double* red = nullptr;    // [red_size(nbk)] reduced system S (lower-triangular 32x32 blocks) | rhs
   double* delta = nullptr;  // [32 nbk] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
+  int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (bit 32: one-wave elimination)
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
   double* cost = nullptr;   // [kStatSlots] sum |b - f|^2 over this problem's observations at the start of iteration i
@@ -126,8 +127,9 @@ struct sfm_ba_problem {
   int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
   int lin_grid = 0;          // workgroups of the last ba_linearize (rows of cost_ws)
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
-  bool backsub_pending = false;   // the reduced solve ran, its back substitution waits for the fused launch
-  bool lin_pending = false;       // inside ba_enqueue_iterations: the next iteration is already linearised
+  bool backsub_pending = false;   // the reduced solve ran, its back substitution waits for the next launch (ba_flush)
+  double pending_lambda = 0;      // ... with these parameters
+  int pending_quirks = 0;
   int max_track = 0;         // longest track (observations of one point)
   int schur_mode = SFM_SCHUR_AUTO;
   int quirks = SFM_QUIRKS_REFERENCE;   // of the linearisation in flight
@@ -150,8 +152,9 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool fused_backsub = false);
-int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks, bool defer_backsub = false);
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
+int ba_flush(sfm_ba_problem* p);      // complete a deferred back substitution
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
 bool ba_can_fuse(const sfm_ba_problem* p);
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras

@@ -448,14 +448,42 @@ bool ba_can_fuse(const sfm_ba_problem* p) {
   return !(p->debug & 16) && sizeof(double) * (size_t)p->dev.V * (19 + 35 + 19 + 7) <= 64 * 1024;
 }
 
-// fused_backsub: the reduced solve of the previous iteration has run with its back substitution deferred
-// (ba_enqueue_solve_update(..., true)); this launch finishes that iteration and linearises the next one.
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool fused_backsub) {
+static int enqueue_backsub(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
-  if (fused_backsub) {
-    if (!p->backsub_pending || !ba_can_fuse(p)) { set_error("internal: fused linearisation without a deferred back substitution"); return SFM_E_HANDLE; }
-  } else {
+  const int g = pick_group(p);
+  const int gpb = 256 / g;
+  int grid = std::min((d.N + gpb - 1) / gpb, 4 * ctx().num_cus);
+  if (grid < 1) grid = 1;
+  const size_t lds = sizeof(double) * (size_t)d.V * (19 + 7);
+  ba_tick(p, SFM_K_BACKSUB, true, s);
+  if (lds <= 64 * 1024) launch_backsub<true>(p, g, grid, lds, s, lambda, quirks);
+  else launch_backsub<false>(p, g, grid, 0, s, lambda, quirks);
+  ba_tick(p, SFM_K_BACKSUB, false, s);
+  SFM_HIP(hipGetLastError());
+  p->red_clean = true;      // ba_backsub_kernel cleared [S | rhs]
+  p->cur ^= 1;              // ba_back_solve_kernel prepared the updated cameras into the other slot
+  return SFM_OK;
+}
+
+// The back substitution of an iteration is DEFERRED when the fused kernel can take it (ba_can_fuse): if the next
+// thing the caller does is linearise again with the same lambda / quirks -- sfm_ba_iterate, or the multi-GPU loop
+// linearize_reduce / all-reduce / solve_update -- it rides in that launch (one pass over the observations per
+// iteration instead of two).  Anything else that looks at or replaces the state first completes it with the
+// stand-alone kernel (ba_flush; also sfm_ba_flush, which sfm_ba_iterate calls before it returns so that every
+// call enqueues complete iterations).
+int ba_flush(sfm_ba_problem* p) {
+  if (!p->backsub_pending) return SFM_OK;
+  p->backsub_pending = false;
+  return enqueue_backsub(p, p->pending_lambda, p->pending_quirks);
+}
+
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+  hipStream_t s = p->stream;
+  const BaDev& d = p->dev;
+  bool fused = p->backsub_pending && ba_can_fuse(p) && lambda == p->pending_lambda && quirks == p->pending_quirks;
+  if (!fused) {
+    SFM_TRY(ba_flush(p));
     if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
     if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * red_size(d.nbk), s));
   }
@@ -474,7 +502,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bo
   }
   const size_t lds_acc = sizeof(double) * (size_t)d.V * 35;
   const int mode = lds <= 64 * 1024 ? 2 : (lds_acc <= 64 * 1024 ? 1 : 0);
-  if (fused_backsub) {
+  if (fused) {
     const size_t lds_f = sizeof(double) * (size_t)d.V * (19 + 35 + 19 + 7);
     if (dense_z) launch_linearize<2, true, true>(p, p->cur ^ 1, g, grid, lds_f, s, lambda, quirks);
     else launch_linearize<2, false, true>(p, p->cur ^ 1, g, grid, lds_f, s, lambda, quirks);
@@ -498,43 +526,30 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bo
   return SFM_OK;
 }
 
-// defer_backsub: stop after the reduced solve; the caller follows with ba_enqueue_linearize_reduce(..., true).
-int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks, bool defer_backsub) {
+int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = p->stream;
-  const BaDev& d = p->dev;
+  SFM_TRY(ba_flush(p));           // a caller that solves twice without linearising in between
   ba_tick(p, SFM_K_SOLVE, true, s);
   SFM_TRY(ba_enqueue_reduced_solve(p, lambda));
   ba_tick(p, SFM_K_SOLVE, false, s);
   SFM_HIP(hipGetLastError());
-  if (defer_backsub) { p->backsub_pending = true; return SFM_OK; }
-  const int g = pick_group(p);
-  const int gpb = 256 / g;
-  int grid = std::min((d.N + gpb - 1) / gpb, 4 * ctx().num_cus);
-  if (grid < 1) grid = 1;
-  const size_t lds = sizeof(double) * (size_t)d.V * (19 + 7);
-  ba_tick(p, SFM_K_BACKSUB, true, s);
-  if (lds <= 64 * 1024) launch_backsub<true>(p, g, grid, lds, s, lambda, quirks);
-  else launch_backsub<false>(p, g, grid, 0, s, lambda, quirks);
-  ba_tick(p, SFM_K_BACKSUB, false, s);
-  SFM_HIP(hipGetLastError());
-  p->red_clean = true;      // ba_backsub_kernel cleared [S | rhs]
-  p->cur ^= 1;      // ba_back_solve_kernel prepared the updated cameras into the other slot
-  return SFM_OK;
+  if (ba_can_fuse(p)) {
+    p->backsub_pending = true;
+    p->pending_lambda = lambda;
+    p->pending_quirks = quirks;
+    return SFM_OK;
+  }
+  return enqueue_backsub(p, lambda, quirks);
 }
 
-// `iters` iterations; between two of them the back substitution rides in the next linearisation's launch.
+// `iters` complete iterations: between two of them the back substitution rides in the next linearisation's launch,
+// the last one is flushed before returning.
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks) {
   for (int it = 0; it < iters; ++it) {
-    if (!p->lin_pending) SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks, false));
-    p->lin_pending = false;
-    const bool fuse = it + 1 < iters && ba_can_fuse(p);
-    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks, fuse));
-    if (fuse) {
-      SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks, true));
-      p->lin_pending = true;
-    }
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
   }
-  return SFM_OK;
+  return ba_flush(p);
 }
 
 // parity hooks (sfm_ba_residual_jacobian / sfm_ba_reduced_system)

@@ -287,6 +287,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
 
 int sfm_ba_set_stream(sfm_ba_problem* p, void* hip_stream) {
   SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
   SFM_HIP(hipStreamSynchronize(p->stream));
   p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx().own;
   return SFM_OK;
@@ -296,11 +297,14 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
   SFM_TRY(check_problem(p));
   switch (option) {
     case SFM_OPT_SCHUR:
+      SFM_TRY(ba_flush(p));
       if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
       p->schur_mode = value;
       return SFM_OK;
     case SFM_OPT_DEBUG:
+      SFM_TRY(ba_flush(p));
       p->debug = value;
+      p->dev.debug = value;
       if ((value & 8) && p->dev.stamps == nullptr) {
         SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->dev.stamps), sizeof(unsigned long long) * 1024));
         SFM_HIP(hipMemset(p->dev.stamps, 0, sizeof(unsigned long long) * 1024));
@@ -310,6 +314,7 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
       p->timing = value;   // bit k set = time kernel class k
       return SFM_OK;
     case SFM_OPT_DETERMINISTIC:
+      SFM_TRY(ba_flush(p));
       if (value != 0) {
         // needs the atomic-free dense product (Zd resident) and the LDS camera accumulators of ba_linearize
         if (!p->schur_mfma_ok) { set_error("deterministic mode needs the dense Schur product, which does not fit this scene"); return SFM_E_SHAPE; }
@@ -337,8 +342,14 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
   }
 }
 
+int sfm_ba_flush(sfm_ba_problem* p) {
+  SFM_TRY(check_problem(p));
+  return ba_flush(p);
+}
+
 int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams) {
   SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
   BaDev& d = p->dev;
   SFM_TRY(ba_upload(p, d.cams, cams, sizeof(double) * 7 * d.V));
   SFM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), p->stream));
@@ -351,6 +362,7 @@ int sfm_ba_set_cameras(sfm_ba_problem* p, const double* cams) {
 int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts) {
   SFM_TRY(check_problem(p));
   BaDev& d = p->dev;
+  SFM_TRY(ba_flush(p));
   if (first < 0 || count < 0 || first + (long long)count > d.N) {
     set_error("sfm_ba_set_points: range [%d, %d) outside the %d points", first, first + count, d.N);
     return SFM_E_SHAPE;
@@ -365,6 +377,7 @@ int sfm_ba_set_points(sfm_ba_problem* p, int first, int count, const double* pts
 
 int sfm_ba_set_state(sfm_ba_problem* p, const double* cams, const double* pts) {
   SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
   BaDev& d = p->dev;
   SFM_TRY(ba_upload(p, d.cams, cams, sizeof(double) * 7 * d.V));
   if (d.N > 0) {
@@ -410,6 +423,7 @@ int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks) {
 
 int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
   SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
   hipStream_t s = p->stream;
   BaDev& d = p->dev;
   if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));     // validates the cameras even with zero iterations (ba:412)
@@ -433,6 +447,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
                   int64_t n_new_obs, const int* obs_cam, const int* obs_pt, const double* uv_norm) {
   SFM_TRY(check_problem(p));
   if (n_new_cams < 0 || n_new_pts < 0 || n_new_obs < 0) { set_error("sfm_ba_append: negative count"); return SFM_E_SHAPE; }
+  SFM_TRY(ba_flush(p));
   BaDev& d = p->dev;
   const int V2 = d.V + n_new_cams, N2 = d.N + n_new_pts;
   const long long M2 = d.M + n_new_obs;
@@ -485,6 +500,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   if (st != SFM_OK) { (void)hipStreamSynchronize(s); sfm_ba_destroy(q); return st; }
   // the handle keeps its identity, options, stream and counters; the old buffers leave with q
   q->schur_mode = p->schur_mode; q->debug = p->debug; q->timing = p->timing; q->quirks = p->quirks;
+  q->dev.debug = p->debug;
   q->deterministic = p->deterministic && q->schur_mfma_ok && sizeof(double) * (size_t)q->dev.V * 35 <= 64 * 1024;
   const bool had_external_red = p->dev.red != p->own_red;
   std::swap(p->dev, q->dev);
@@ -514,6 +530,7 @@ int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubl
 
 int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles) {
   SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));           // the deferred kernel clears the buffer that is bound now
   const int64_t need = (int64_t)red_size(p->dev.nbk);
   p->red_clean = false;
   if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }

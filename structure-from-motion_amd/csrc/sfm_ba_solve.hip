@@ -72,7 +72,7 @@ __device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], f64x2 (*xy)[64],
     const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
     if (s > 0) {                                    // deferred update with pair s-1 (its x, y are a[j-2], a[j-1])
 #pragma unroll
-      for (int k = j + 2; k < NB; ++k) a[k] -= a[j - 2] * prev[k].x + a[j - 1] * prev[k].y;
+      for (int k = j + 2; k < NB; ++k) a[k] = __builtin_fma(-a[j - 1], prev[k].y, __builtin_fma(-a[j - 2], prev[k].x, a[k]));
     }
     const double x = a[j] * r1;
     const double y = (a[j + 1] - x * l21) * i22;
@@ -80,12 +80,64 @@ __device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], f64x2 (*xy)[64],
     if (j + 2 < NB) {
       const double x2 = lane_bcast(x, j + 2), y2 = lane_bcast(y, j + 2);
       const double x3 = lane_bcast(x, j + 3), y3 = lane_bcast(y, j + 3);
-      a[j + 2] -= x * x2 + y * y2;
-      a[j + 3] -= x * x3 + y * y3;
+      a[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, a[j + 2]));      // two chained FMAs: one instruction fewer than
+      a[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, a[j + 3]));      // mul + fma + sub on an issue-bound wave
     }
     xy[s][lane] = f64x2{x, y};
 #pragma unroll
     for (int k = j + 4; k < NB; ++k) prev[k] = xy[s][k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same elimination spread over the FOUR waves of the column workgroup (one per SIMD).  A single wave issues
+// one FP64 instruction every ~7 cycles whatever the dependencies (measured: tools/microbench_solve.hip), so the
+// one-wave version above is bound by its ~85 instructions per pair-step, half of them the update of the far
+// columns.  Here wave w owns columns 8w .. 8w+7 of all 64 rows (lane = row as above, 8 registers).  The pivot chain
+// walks through the waves: wave `seg` runs the four pair-steps of its columns (pivot broadcast, the two reciprocal
+// square roots, x / y of every row, its own remaining columns) and publishes (x, y) of every row in LDS followed
+// by a step counter; the waves to its right apply each published step to their eight columns as it appears
+// (one 16-byte broadcast read + two FMAs per column) and take the chain over once it reaches them.  The flag and the
+// data are LDS writes of one wave, which the LDS executes in order; readers poll the counter, then read.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chol_trsm_cols(double (&c)[8], f64x2 (*xy)[64], int* flag, int lane, int wave) {
+#pragma unroll
+  for (int seg = 0; seg < 4; ++seg) {
+    if (wave == seg) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = 2 * t, s = 4 * seg + t, l0 = 8 * seg + j;      // l0: the lane that holds row (= column) 8 seg + j of D
+        const double pa = lane_bcast(c[j], l0), pb = lane_bcast(c[j], l0 + 1), pc = lane_bcast(c[j + 1], l0 + 1);
+        const double det = __builtin_fma(pa, pc, -(pb * pb));
+        const double r1 = rsqrt_nr(pa), r2 = rsqrt_nr(det);
+        const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
+        const double x = c[j] * r1;
+        const double y = (c[j + 1] - x * l21) * i22;
+        c[j] = x; c[j + 1] = y;
+        xy[s][lane] = f64x2{x, y};
+        if (t < 3) {
+          // the next pair's two columns at once through register broadcasts, my other columns through LDS
+          const double x2 = lane_bcast(x, l0 + 2), y2 = lane_bcast(y, l0 + 2);
+          const double x3 = lane_bcast(x, l0 + 3), y3 = lane_bcast(y, l0 + 3);
+          c[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, c[j + 2]));
+          c[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, c[j + 3]));
+#pragma unroll
+          for (int u = j + 4; u < 8; ++u) { const f64x2 q = xy[s][8 * seg + u]; c[u] = __builtin_fma(-y, q.y, __builtin_fma(-x, q.x, c[u])); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else if (wave > seg) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int s = 4 * seg + t;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const f64x2 own = xy[s][lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const f64x2 q = xy[s][8 * wave + u]; c[u] = __builtin_fma(-own.y, q.y, __builtin_fma(-own.x, q.x, c[u])); }
+      }
+    }
   }
 }
 
@@ -147,7 +199,7 @@ __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, i
 
 __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
   constexpr int kSq = NB * (NB + 1);
-  __shared__ __attribute__((aligned(16))) double arena[2 * kSq + (NB / 2) * 64 * 2];
+  __shared__ __attribute__((aligned(16))) double arena[2 * kSq + (NB / 2) * 64 * 2 + 2];
   const int P = d.P, nbk = d.nbk;
   // workgroups 0 .. nbk-j are the column role (block rows j .. nbk, the last one being the rhs row); the rest are
   // trailing super-tiles (sr >= sc)
@@ -161,6 +213,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
   double(*Tm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena);
   double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + kSq);
   f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(arena + 2 * kSq);     // [pair-step][lane] = (x, y)
+  int* flag = reinterpret_cast<int*>(arena + 2 * kSq + (NB / 2) * 64 * 2);      // pair-steps published (multi-wave elimination)
   static_assert((2 * kSq) % 2 == 0, "xy must be 16-byte aligned");
   const int r = j + blockIdx.x;
   const bool is_rhs = r == nbk;
@@ -228,12 +281,43 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       Dm[i][ocol] = dv;
     }
   }
+  if (tid == 0) *flag = 0;
   if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
-  if (tid >= 64) return;
-  double a[NB];
   const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
   const int row = lane & (NB - 1);
+  if (!(d.debug & 32)) {
+    // four-wave elimination: this wave's eight columns of all 64 rows
+    unsigned long long* stamp3 = (d.stamps && blockIdx.x == 1 && tid == 192) ? d.stamps + 8 * j : nullptr;
+    double c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = src[row][8 * wave + u];
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+    chol_trsm_cols(c, xy, flag, lane, wave);
+    if (stamp3) { asm volatile("" :: "v"(c[7])); stamp3[4] = __builtin_amdgcn_s_memtime(); }
+    if (lane >= NB) {
+      if (r == j) {
+        // row `row` of X = L_d^-T (upper triangular), stored k-major: ldiag[j][k][i] = X[i][k]
+        double* out = d.ldiag + (size_t)j * NB * NB + row;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = 8 * wave + u; out[k * NB] = (k >= row) ? c[u] : 0.0; }
+      } else if (is_rhs) {
+        if (row == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rhs[c0 + 8 * wave + u] = c[u];
+        }
+      } else {
+        // columns 8 wave .. 8 wave + 7 of row `row` of L[r][j]: four (k, k + 4) pairs of the k-interleaved block
+        double* out = Tblk + wave * 256 + row * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f64x2*>(out + q * 64) = f64x2{c[q], c[q + 4]};
+      }
+    }
+    if (stamp3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp3[5] = __builtin_amdgcn_s_memtime(); }
+    return;
+  }
+  if (tid >= 64) return;
+  double a[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) a[k] = src[row][k];
   if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
@@ -268,50 +352,53 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// L^T dp = y (y sits in rhs after the column steps), blocked back substitution in one 8-wave workgroup:
-// per block b, wave 0 computes x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the factorisation left
-// in ldiag (both halves of the wave take half of the k range each; the next block's factor is prefetched) while
-// the other seven waves hold the L values of block row b in registers -- thread (block bi above, pair q) owns
-// columns c and c + 4 of block (b, bi), 32 x 16 contiguous bytes in the block layout, 32 independent loads issued
-// before x_b exists -- and fold x_b into their y.  448 update threads cover 28 block rows (896 unknowns) from
-// registers; larger systems take further rounds of 28 whose loads start once x_b is known.  Then the camera
-// update of ba:383-392 and the preparation of the next iteration.
+// L^T dp = y (y sits in rhs after the column steps): blocked back substitution.
+//
+// ba_back_solve: one 8-wave workgroup handles a GROUP of up to 28 block rows [b_lo, b_hi), last block first.  Per
+// block b, wave 0 computes x_b = L_d^-T y_b as a 32x32 mat-vec with the inverse factor the factorisation left in
+// ldiag (both halves of the wave take half of the k range each; the next block's factor is prefetched) while the
+// other seven waves hold the L values of block row b in registers -- thread (block bi above, pair q) owns columns c
+// and c + 4 of block (b, bi), 32 x 16 contiguous bytes in the block layout, 32 independent loads issued before x_b
+// exists -- and fold x_b into their y.  448 update threads cover the 28 block rows of a group (896 unknowns) from
+// registers.  The group that ends at row 0 also does the camera update of ba:383-392 and prepares the next
+// iteration's cameras.
+// ba_back_update: between two groups, y[0 : 32 g0) -= L[g0 : g1, 0 : g0)^T x[g0 : g1) -- the part of the sweep that
+// is a plain (transposed) matrix-vector product, one workgroup per block column so that it streams L at the
+// chip's bandwidth instead of one CU's (a single workgroup reading the 8 MB of L at V = 200 took 250 us).
+// Systems of up to 28 block rows (V <= 128) are one group and one launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int BS_THREADS = 512;
 constexpr int BS_UPD = BS_THREADS - 64;        // update threads
-constexpr int BS_ROWS = BS_UPD / 16;           // block rows one round covers (16 column pairs per block)
+constexpr int BS_ROWS = BS_UPD / 16;           // block rows a group covers (16 column pairs per block)
 
-template <bool Y_LDS>
-__global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int cur) {
-  extern __shared__ double ylds[];     // [32 nbk] working copy of y when it fits (Y_LDS)
+__global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int cur, int b_hi, int b_lo) {
+  __shared__ double ylds[BS_ROWS * NB];     // y of the group's rows
   __shared__ double xb[NB];
   __shared__ double yb[NB];
   const int P = d.P, nbk = d.nbk;
   const double* red = d.red;
-  double* yg = d.red + red_rhs_off(nbk);
+  const double* yg = d.red + red_rhs_off(nbk);
   const int tid = threadIdx.x;
   const int lane = tid & (NB - 1);
-  if (Y_LDS) {
-    for (int i = tid; i < nbk * NB; i += BS_THREADS) ylds[i] = yg[i];
-  }
-  auto yref = [&](int i) -> double& { return Y_LDS ? ylds[i] : yg[i]; };
-  // wave 0: lane l holds half a row of L_d^-T: row l & 31, k in [16 (l >> 5), 16 (l >> 5) + 16)
+  const int y0 = b_lo * NB;
+  for (int i = tid; i < (b_hi - b_lo) * NB; i += BS_THREADS) ylds[i] = yg[y0 + i];
+  // wave 0: lane l holds half a row of L_d^-T: row l & 31, k in [16 (l >> 5), 16 (l >> 5) + 16).
+  // One register array for both roles: wave 0 keeps that half row in v[0..15].x across the block loop, the update
+  // waves reload v for every block.
   const int khalf = (tid >> 5) & 1;
-  // one register array for both roles: wave 0 keeps its half row of the diagonal factor in v[0..15].x (across the
-  // block loop), the update waves reload v for every block
   f64x2 v[NB];
   if (tid < 64) {
-    const double* Xd = d.ldiag + (size_t)(nbk - 1) * NB * NB + (size_t)khalf * 16 * NB;
+    const double* Xd = d.ldiag + (size_t)(b_hi - 1) * NB * NB + (size_t)khalf * 16 * NB;
 #pragma unroll
     for (int k = 0; k < NB / 2; ++k) v[k].x = Xd[k * NB + lane];
   }
   __syncthreads();
   unsigned long long* stamp = (d.stamps && tid == 0) ? d.stamps + 128 : nullptr;
   const int utid = tid - 64;            // 0 .. BS_UPD-1 for the update waves
-  const int ubi = utid >> 4, uq = utid & 15;
+  const int ubi = b_lo + (utid >> 4), uq = utid & 15;     // block row this thread updates
   const int ucol = (uq & 3) + 8 * (uq >> 2);              // columns ucol and ucol + 4 of a block
   const int uoff = (uq >> 2) * 256 + (uq & 3) * 64;       // + 2 k: that column pair in row k of the block
-  for (int b = nbk - 1; b >= 0; --b) {
+  for (int b = b_hi - 1; b >= b_lo; --b) {
     const int c0 = b * NB;
     if (stamp && b < 16) stamp[4 * b + 0] = __builtin_amdgcn_s_memtime();
     if (tid >= 64) {
@@ -321,7 +408,7 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
         for (int k = 0; k < NB; ++k) v[k] = *reinterpret_cast<const f64x2*>(blk + 2 * k);     // L[c0 + k][32 ubi + ucol (+4)]
       }
     } else {
-      if (tid < NB) yb[lane] = (c0 + lane < P) ? yref(c0 + lane) : 0.0;      // single wave: LDS in order
+      if (tid < NB) yb[lane] = (c0 + lane < P) ? ylds[c0 - y0 + lane] : 0.0;      // single wave: LDS in order
       double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
 #pragma unroll
       for (int k = 0; k < NB / 2; k += 4) {
@@ -332,10 +419,10 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
       xi += __shfl_xor(xi, 32, 64);
       if (tid < NB) {
         xb[lane] = (c0 + lane < P) ? xi : 0.0;
-        if (c0 + lane < P) d.delta[c0 + lane] = xi;
+        d.delta[c0 + lane] = (c0 + lane < P) ? xi : 0.0;
       }
       if (stamp && b < 16) stamp[4 * b + 1] = __builtin_amdgcn_s_memtime();
-      if (b > 0) {                       // next diagonal factor; lands during the update below
+      if (b > b_lo) {                    // next diagonal factor; lands during the update below
         const double* Xd = d.ldiag + (size_t)(b - 1) * NB * NB + (size_t)khalf * 16 * NB;
 #pragma unroll
         for (int k = 0; k < NB / 2; ++k) v[k].x = Xd[k * NB + lane];
@@ -343,32 +430,17 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
     }
     __syncthreads();
     if (stamp && b < 16) stamp[4 * b + 2] = __builtin_amdgcn_s_memtime();
-    if (tid >= 64) {
-      if (ubi < b) {
-        double s0 = 0, s1 = 0;
+    if (tid >= 64 && ubi < b) {
+      double s0 = 0, s1 = 0;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { s0 += v[k].x * xb[k]; s1 += v[k].y * xb[k]; }
-        yref(NB * ubi + ucol) -= s0;
-        yref(NB * ubi + ucol + 4) -= s1;
-      }
-      for (int bi = ubi + BS_ROWS; bi < b; bi += BS_ROWS) {      // block rows beyond the 28 held in registers
-        const double* blk = red + red_blk_base(b, bi) + uoff;
-        double s0 = 0, s1 = 0;
-#pragma unroll 1
-        for (int kc = 0; kc < NB; kc += 16) {      // 16 loads in flight at a time
-          f64x2 w[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) w[k] = *reinterpret_cast<const f64x2*>(blk + 2 * (kc + k));
-#pragma unroll
-          for (int k = 0; k < 16; ++k) { s0 += w[k].x * xb[kc + k]; s1 += w[k].y * xb[kc + k]; }
-        }
-        yref(NB * bi + ucol) -= s0;
-        yref(NB * bi + ucol + 4) -= s1;
-      }
+      for (int k = 0; k < NB; ++k) { s0 += v[k].x * xb[k]; s1 += v[k].y * xb[k]; }
+      ylds[NB * (ubi - b_lo) + ucol] -= s0;
+      ylds[NB * (ubi - b_lo) + ucol + 4] -= s1;
     }
     __syncthreads();
     if (stamp && b < 16) stamp[4 * b + 3] = __builtin_amdgcn_s_memtime();
   }
+  if (b_lo > 0) return;
   if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
   for (int c = tid; c < d.V; c += BS_THREADS) {
     double cam[7];
@@ -380,6 +452,35 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
     const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
     d.prep[cur ^ 1][c] = out;
     report_status(d.status, st, c);
+  }
+}
+
+// y[32 bi ..] -= sum_{r = g0}^{g1 - 1} L[r][bi]^T x_r for block column bi = blockIdx.x < g0 (x in d.delta).
+// Thread (slice, q): block rows r = g0 + slice, + 16, ...; the column pair q of every one of them.
+__global__ __launch_bounds__(256) void ba_back_update_kernel(BaDev d, int g0, int g1) {
+  __shared__ double part[16][NB + 1];
+  const int bi = blockIdx.x;
+  const int tid = threadIdx.x, uq = tid & 15, slice = tid >> 4;
+  const int ucol = (uq & 3) + 8 * (uq >> 2);
+  const int uoff = (uq >> 2) * 256 + (uq & 3) * 64;
+  double s0 = 0, s1 = 0;
+  for (int r = g0 + slice; r < g1; r += 16) {
+    const double* blk = d.red + red_blk_base(r, bi) + uoff;
+    const double* x = d.delta + r * NB;
+    f64x2 w[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) w[k] = *reinterpret_cast<const f64x2*>(blk + 2 * k);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { const double xk = x[k]; s0 += w[k].x * xk; s1 += w[k].y * xk; }
+  }
+  part[slice][ucol] = s0;
+  part[slice][ucol + 4] = s1;
+  __syncthreads();
+  if (tid < NB) {
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][tid];
+    d.red[red_rhs_off(d.nbk) + bi * NB + tid] -= s;
   }
 }
 
@@ -402,9 +503,16 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
     const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
     ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2, 256, 0, s>>>(d, j, lambda);
   }
-  const size_t ybytes = sizeof(double) * (size_t)nbk * NB;
-  if (ybytes <= 48 * 1024) ba_back_solve_kernel<true><<<1, BS_THREADS, ybytes, s>>>(d, p->cur);
-  else ba_back_solve_kernel<false><<<1, BS_THREADS, 0, s>>>(d, p->cur);
+  // back substitution in groups of at most 28 block rows, from the bottom; between two groups one multi-workgroup
+  // launch folds the finished group into everything above it
+  const int ngroups = (nbk + BS_ROWS - 1) / BS_ROWS;
+  const int gsize = (nbk + ngroups - 1) / ngroups;
+  for (int hi = nbk; hi > 0;) {
+    const int lo = std::max(0, hi - gsize);
+    ba_back_solve_kernel<<<1, BS_THREADS, 0, s>>>(d, p->cur, hi, lo);
+    if (lo > 0) ba_back_update_kernel<<<lo, 256, 0, s>>>(d, lo, hi);
+    hi = lo;
+  }
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }

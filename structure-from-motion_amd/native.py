@@ -32,7 +32,7 @@ EXPORTS = (
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
-    "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points", "sfm_ba_get_stats",
+    "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points", "sfm_ba_get_stats", "sfm_ba_flush",
     "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
@@ -86,6 +86,7 @@ def load():
     lib.sfm_ba_iterate.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int]
     lib.sfm_ba_linearize_reduce.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
     lib.sfm_ba_solve_update.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+    lib.sfm_ba_flush.argtypes = [ctypes.c_void_p]
     lib.sfm_ba_kernel_time.argtypes = [ctypes.c_void_p, ctypes.c_int, _dp, _ip]
     lib.sfm_ba_reset_timing.argtypes = [ctypes.c_void_p]
     lib.sfm_ba_reduced_buffer.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
@@ -428,6 +429,10 @@ class BaProblem:
 
     def solve_update(self, lam, quirks=QUIRKS_REFERENCE):
         check(self._lib.sfm_ba_solve_update(self._h, float(lam), int(quirks)))
+
+    def flush(self):
+        """Complete the back substitution ``solve_update`` may have left to the next linearisation (sfm_ba_flush)."""
+        check(self._lib.sfm_ba_flush(self._h))
 
     def get_stats(self, max_iters=256):
         """Per-iteration cost sum |b - f|^2 (normalised image coordinates) at the start of every iteration run since

@@ -140,6 +140,9 @@ class HipShardEngine:
     def solve_update(self, lam, quirks=native.QUIRKS_REFERENCE):
         self.prob.solve_update(lam, quirks)
 
+    def flush(self):
+        self.prob.flush()
+
     def get_state(self):
         return self.prob.get_state()
 
@@ -164,3 +167,6 @@ class ShardedBa:
                 if self.all_reduce is not None:
                     self.all_reduce(buf)
                 self.engine.solve_update(lam, quirks)
+            flush = getattr(self.engine, "flush", None)       # the device engine may have deferred the last
+            if flush is not None:                              # back substitution to a linearisation that never comes
+                flush()
