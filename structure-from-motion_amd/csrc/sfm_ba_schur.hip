@@ -327,8 +327,11 @@ __host__ __device__ inline SchurTileRef plan_locate(const SchurPlan& pl, int w) 
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_WAVES = 16;                      // the per-visit work is tiny at low visibility: occupancy hides it
 constexpr int PAIR_THREADS = 64 * PAIR_WAVES;
-constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubles)
-constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP;
+constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubles) of the row-lane kernel (v1)
+constexpr int TP2 = 135;                            // pitch of the entry-lane kernel: 7 (mod 32) doubles, so the 49 entries
+                                                    // (i TP2 + j) of a 7x7 camera-pair block hit 7 i + j = 0..48 -> at most two per bank
+constexpr int KMAX = 6;                             // observations per side an entry-lane visit keeps in registers
+constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP2;
 
 // One (point, tile) visit by one wave.  Lanes = (observation b of block B, column j): each keeps its three
 // Z values and its tile column in registers.  The A side is wave-uniform: the wave walks the observations a of
@@ -420,6 +423,91 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Entry-lane form of the same product (default).  Lane (i, j), i = lane / 7, j = lane % 7 (49 of 64 lanes), owns
+// entry (i, j) of EVERY 7x7 camera-pair block of a visit: block (a, b) contributes sum_t Z_a[i][t] Z_b[j][t] -- three
+// FMAs and one ds_add_f64 per camera pair, with 49 lanes busy whatever the visibility (the row-lane form above keeps
+// 7 k_B lanes busy: 19 of 64 at the 15 % of BASELINE config 4, and spends 45 instructions per A-observation).
+// A visit loads row i of up to KMAX A-side blocks and row j of up to KMAX B-side blocks straight into registers
+// (24 bytes per lane and observation, 7 distinct addresses per instruction: the record of one observation is
+// 168 contiguous bytes) and then runs a fully unrolled, wave-uniformly predicated loop over the camera pairs, so
+// nothing is re-read per pair; longer block tracks take further KMAX x KMAX chunks.  Tile rows / columns of the
+// observations' cameras sit in two lanes' registers and come back through v_readlane with the loop counters.
+// ---------------------------------------------------------------------------------------------
+template <bool DIAG>
+__device__ __forceinline__ void pairs_tile_body_v2(const BaDev& d, const int* __restrict__ blk_ptr, int nblk, int ti, int tj,
+                                                   int p_beg, int p_end, double* __restrict__ slab, double* __restrict__ tile) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nr = 7 * min(CB, d.V - ti * CB), nc = 7 * min(CB, d.V - tj * CB);      // used part of the tile
+  for (int t = tid; t < nr * TP2; t += PAIR_THREADS) tile[t] = 0.0;
+  __syncthreads();
+  const double* __restrict__ Z = d.Z;
+  const int* __restrict__ cam_idx = d.cam_idx;
+  const bool on = lane < 49;
+  const int li = on ? lane / 7 : 0, lj = on ? lane - 7 * (lane / 7) : 0;
+  double* tlane = tile + li * TP2 + lj;
+  // lanes 0..3 fetch bp[ti], bp[ti+1], bp[tj], bp[tj+1] of a point
+  auto fetch_bp = [&](int p) -> int {
+    if (p >= p_end) return 0;
+    const int which = lane & 3;
+    return blk_ptr[(size_t)p * (nblk + 1) + ((which & 2) ? tj : ti) + (which & 1)];
+  };
+  int p = p_beg + wave;
+  int bp1 = fetch_bp(p);
+  int bp2 = fetch_bp(p + PAIR_WAVES);
+  for (; p < p_end; p += PAIR_WAVES) {
+    const int bp3 = fetch_bp(p + 2 * PAIR_WAVES);          // block offsets two visits ahead
+    const int a0 = __builtin_amdgcn_readlane(bp1, 0), kA = __builtin_amdgcn_readlane(bp1, 1) - a0;
+    const int b0 = __builtin_amdgcn_readlane(bp1, 2), kB = __builtin_amdgcn_readlane(bp1, 3) - b0;
+    bp1 = bp2; bp2 = bp3;
+    if (kA <= 0 || kB <= 0) continue;
+    for (int ac = 0; ac < kA; ac += KMAX) {
+      const int na = min(KMAX, kA - ac);
+      for (int bc = 0; bc < (DIAG ? ac + 1 : kB); bc += KMAX) {      // diagonal tile: blocks with b <= a only
+        const int nb = min(KMAX, kB - bc);
+        // tile row offset of A observation l (lanes 0..5), tile column of B observation l (lanes 8..13)
+        int off = 0;
+        if (lane < na) off = 7 * TP2 * (cam_idx[a0 + ac + lane] - ti * CB);
+        else if (lane >= 8 && lane < 8 + nb) off = 7 * (cam_idx[b0 + bc + lane - 8] - tj * CB);
+        double za[KMAX][3], zb[KMAX][3];
+#pragma unroll
+        for (int a = 0; a < KMAX; ++a) {
+          if (a < na) {                                     // wave-uniform
+            const double* q = Z + (size_t)(a0 + ac + a) * 21 + 3 * li;
+            za[a][0] = q[0]; za[a][1] = q[1]; za[a][2] = q[2];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < KMAX; ++b) {
+          if (b < nb) {
+            const double* q = Z + (size_t)(b0 + bc + b) * 21 + 3 * lj;
+            zb[b][0] = q[0]; zb[b][1] = q[1]; zb[b][2] = q[2];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < KMAX; ++a) {
+          if (a < na) {
+            double* trow = tlane + __builtin_amdgcn_readlane(off, a);
+#pragma unroll
+            for (int b = 0; b < KMAX; ++b) {
+              if (b < nb && (!DIAG || bc + b <= ac + a)) {
+                const double val = za[a][0] * zb[b][0] + za[a][1] * zb[b][1] + za[a][2] * zb[b][2];
+                if (on) atomicAdd(trow + __builtin_amdgcn_readlane(off, 8 + b), val);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < nr * nc; t += PAIR_THREADS) {        // ba_schur_reduce never reads beyond the last camera
+    const int r = t / nc, c = t - r * nc;
+    slab[r * RB + c] = tile[r * TP2 + c];
+  }
+}
+
 __global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, const int* __restrict__ blk_ptr,
                                                                      double* __restrict__ ws, SchurPlan plan) {
   extern __shared__ double lds_pairs[];
@@ -429,8 +517,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, c
   const SchurTileRef t = plan_locate(plan, w);
   const int p_beg = t.chunk * plan.rpc[t.cls];
   const int p_end = min(d.N, p_beg + plan.rpc[t.cls]);
-  if (t.ti != t.tj) pairs_tile_body<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
-  else pairs_tile_body<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
+  if (d.debug & 64) {          // the row-lane form, kept for A/B runs
+    if (t.ti != t.tj) pairs_tile_body<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
+    else pairs_tile_body<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
+    return;
+  }
+  if (t.ti != t.tj) pairs_tile_body_v2<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
+  else pairs_tile_body_v2<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
 }
 
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
@@ -660,7 +753,7 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     ba_tick(p, SFM_K_SCHUR, true, s);
     // a scene with fewer than 18 cameras uses only part of the tile: a smaller LDS footprint lets several
     // workgroups share a CU (small scenes are latency-bound)
-    const size_t lds = sizeof(double) * (size_t)7 * std::min(CB, d.V) * TP;
+    const size_t lds = sizeof(double) * (size_t)7 * std::min(CB, d.V) * TP2;
     ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, lds, s>>>(d, p->schur_blk_ptr, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
   }
