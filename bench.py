@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--pts", type=int, default=None, help="override points per rank (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--schur", default="auto", choices=["auto", "pairs", "mfma"])
+    ap.add_argument("--schur", default="auto", choices=["auto", "pairs", "mfma", "rows"])
     args = ap.parse_args()
 
     import torch
@@ -159,7 +159,7 @@ def main():
     ptr_l, cam_l, uv_l, pts_l, (p0, p1) = sfm.sharding.local_shard(scene.pt_ptr, scene.cam_idx, uvn, scene.pts_init, bounds, rank)
 
     engine = sfm.sharding.HipShardEngine(scene.n_cams, ptr_l, cam_l, uv_l, device)
-    schur_mode = {"auto": native.SCHUR_AUTO, "pairs": native.SCHUR_PAIRS, "mfma": native.SCHUR_MFMA}[args.schur]
+    schur_mode = {"auto": native.SCHUR_AUTO, "pairs": native.SCHUR_PAIRS, "mfma": native.SCHUR_MFMA, "rows": native.SCHUR_ROWS}[args.schur]
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
     all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_dist else None
     ba = sfm.sharding.ShardedBa(engine, all_reduce, world)
@@ -225,10 +225,11 @@ def main():
         roofline = dict(kernel="ba_" + dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=achieved / HBM_PEAK_GBS)
     # which Schur product the library launched is asked of the library, not guessed from the flags
-    schur_kernel = "ba_schur_mfma" if engine.prob.info(native.INFO_SCHUR_KERNEL) == native.SCHUR_MFMA else "ba_schur_pairs"
+    schur_kernel = {native.SCHUR_MFMA: "ba_schur_mfma", native.SCHUR_PAIRS: "ba_schur_pairs",
+                    native.SCHUR_ROWS: "ba_schur_rows"}[engine.prob.info(native.INFO_SCHUR_KERNEL)]
     if dominant == "schur":      # the product kernel alone is bracketed (ba_schur_reduce is its own class)
         roofline["kernel"] = schur_kernel
-        if schur_kernel == "ba_schur_pairs":     # no MFMA in it: every product is one ds_add_f64 into the LDS tile
+        if schur_kernel != "ba_schur_mfma":      # no MFMA in the sparse products: every product is one ds_add_f64 into an LDS tile / panel
             achieved = c["lds_adds"] / (dom_avg_ms * 1e-3) / 1e12
             roofline.update(bound="lds", achieved=achieved, peak=LDS_ADD_PEAK_TADDS, unit="Tadd/s", frac=achieved / LDS_ADD_PEAK_TADDS)
     roofline["avg_launch_ms"] = dom_avg_ms

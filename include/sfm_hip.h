@@ -53,12 +53,14 @@ extern "C" {
 #define SFM_Q13_PNP_LOC_SIGN_UNDEFINED 0
 
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
-#define SFM_SCHUR_AUTO    0  /* dense MFMA product at high visibility, sparse LDS-tile product otherwise (fitted cost models) */
-#define SFM_SCHUR_PAIRS   1  /* sparse product: only camera pairs that share a point, accumulated in LDS tiles */
-#define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged) */
+#define SFM_SCHUR_AUTO    0  /* the cheapest of the three below by cost models fitted on MI355X */
+#define SFM_SCHUR_PAIRS   1  /* sparse product over 18 x 18-camera LDS tiles: only camera pairs that share a point (small scenes) */
+#define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged; high visibility) */
+#define SFM_SCHUR_ROWS    3  /* sparse product over LDS row panels: one observation owns its camera's block row of its point's
+                              * contribution (many cameras at low visibility: BASELINE config 4) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 32 = one-wave elimination in ba_chol_step, 64 = row-lane form of the sparse Schur product: results unchanged) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 32 = one-wave elimination in ba_chol_step, 128 = never pick the row-panel sparse product: results unchanged) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit

@@ -141,16 +141,31 @@ struct sfm_ba_problem {
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
   int* schur_blk_ptr = nullptr;  // [N][nblk + 1] first observation of a point in each 18-camera block (sparse path)
   bool schur_mfma_ok = false;
+  // row-panel sparse product (sfm_ba_schur_rows.hip): camera-major observation list and work split, built on first use
+  bool rows_built = false, rows_ok = false;
+  int* cam_ptr = nullptr;                  // [V+1] device
+  void* cam_ent = nullptr;                 // [M] device int4: the observations grouped by camera (observation, first of its track, camera, k_B)
+  unsigned long long* cam_pairs = nullptr; // [V] device: camera pairs the observations of a camera own
+  std::vector<int> h_cam_ptr;
+  std::vector<unsigned long long> h_cam_pairs;
+  void* rows_table = nullptr;              // [rows_wgs] workgroup -> (camera group, observation range)
+  int* rows_first = nullptr;               // [groups+1] first workgroup of every camera group
+  void* rows_ws = nullptr;                 // [rows_wgs][7 R][tpr] split-K panels
+  int rows_R = 0, rows_tpr = 0, rows_wgs = 0, rows_groups = 0;
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 
 namespace sfm {
 int ba_schur_plan(sfm_ba_problem* p);
+int ba_rows_enqueue_build(sfm_ba_problem* p);
+int ba_rows_plan(sfm_ba_problem* p);
+int ba_rows_enqueue(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_structure(sfm_ba_problem* p);      // validate the CSR, fill obs_pt / per-point block offsets / longest track (device)
 int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
 void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
+int ba_schur_choice(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);

@@ -276,7 +276,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
                   d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
-                  p->schur_ws, p->schur_blk_ptr};
+                  p->schur_ws, p->schur_blk_ptr, p->cam_ptr, p->cam_ent, p->cam_pairs, p->rows_table, p->rows_first, p->rows_ws};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -298,7 +298,7 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
   switch (option) {
     case SFM_OPT_SCHUR:
       SFM_TRY(ba_flush(p));
-      if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_MFMA) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
+      if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_ROWS) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
       p->schur_mode = value;
       return SFM_OK;
     case SFM_OPT_DEBUG:
@@ -332,7 +332,7 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
   SFM_TRY(check_problem(p));
   if (value == nullptr) { set_error("sfm_ba_info: value is null"); return SFM_E_SHAPE; }
   switch (what) {
-    case SFM_INFO_SCHUR_KERNEL: *value = ba_schur_uses_mfma(p) ? SFM_SCHUR_MFMA : SFM_SCHUR_PAIRS; return SFM_OK;
+    case SFM_INFO_SCHUR_KERNEL: *value = ba_schur_choice(p); return SFM_OK;
     case SFM_INFO_UPLOAD_BYTES: *value = p->upload_bytes; return SFM_OK;
     case SFM_INFO_N_CAMS: *value = p->dev.V; return SFM_OK;
     case SFM_INFO_N_PTS: *value = p->dev.N; return SFM_OK;
@@ -508,6 +508,11 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   std::swap(p->schur_ws, q->schur_ws);
   std::swap(p->schur_blk_ptr, q->schur_blk_ptr);
   std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
+  std::swap(p->rows_built, q->rows_built); std::swap(p->rows_ok, q->rows_ok);
+  std::swap(p->cam_ptr, q->cam_ptr); std::swap(p->cam_ent, q->cam_ent); std::swap(p->cam_pairs, q->cam_pairs);
+  std::swap(p->rows_table, q->rows_table); std::swap(p->rows_first, q->rows_first); std::swap(p->rows_ws, q->rows_ws);
+  std::swap(p->rows_R, q->rows_R); std::swap(p->rows_tpr, q->rows_tpr); std::swap(p->rows_wgs, q->rows_wgs);
+  std::swap(p->rows_groups, q->rows_groups);
   std::swap(p->max_track, q->max_track);
   // an externally bound reduced buffer has the wrong size when cameras were added: the library's own buffer takes
   // over and the caller binds a new one (sfm_ba_reduced_buffer reports the new size); with the camera count

@@ -327,11 +327,8 @@ __host__ __device__ inline SchurTileRef plan_locate(const SchurPlan& pl, int w) 
 // ---------------------------------------------------------------------------------------------
 constexpr int PAIR_WAVES = 16;                      // the per-visit work is tiny at low visibility: occupancy hides it
 constexpr int PAIR_THREADS = 64 * PAIR_WAVES;
-constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubles) of the row-lane kernel (v1)
-constexpr int TP2 = 135;                            // pitch of the entry-lane kernel: 7 (mod 32) doubles, so the 49 entries
-                                                    // (i TP2 + j) of a 7x7 camera-pair block hit 7 i + j = 0..48 -> at most two per bank
-constexpr int KMAX = 6;                             // observations per side an entry-lane visit keeps in registers
-constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP2;
+constexpr int TP = 7 * CB + 1;                      // LDS tile pitch (127 doubles)
+constexpr size_t kPairLdsBytes = sizeof(double) * (size_t)7 * CB * TP;
 
 // One (point, tile) visit by one wave.  Lanes = (observation b of block B, column j): each keeps its three
 // Z values and its tile column in registers.  The A side is wave-uniform: the wave walks the observations a of
@@ -423,91 +420,6 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Entry-lane form of the same product (default).  Lane (i, j), i = lane / 7, j = lane % 7 (49 of 64 lanes), owns
-// entry (i, j) of EVERY 7x7 camera-pair block of a visit: block (a, b) contributes sum_t Z_a[i][t] Z_b[j][t] -- three
-// FMAs and one ds_add_f64 per camera pair, with 49 lanes busy whatever the visibility (the row-lane form above keeps
-// 7 k_B lanes busy: 19 of 64 at the 15 % of BASELINE config 4, and spends 45 instructions per A-observation).
-// A visit loads row i of up to KMAX A-side blocks and row j of up to KMAX B-side blocks straight into registers
-// (24 bytes per lane and observation, 7 distinct addresses per instruction: the record of one observation is
-// 168 contiguous bytes) and then runs a fully unrolled, wave-uniformly predicated loop over the camera pairs, so
-// nothing is re-read per pair; longer block tracks take further KMAX x KMAX chunks.  Tile rows / columns of the
-// observations' cameras sit in two lanes' registers and come back through v_readlane with the loop counters.
-// ---------------------------------------------------------------------------------------------
-template <bool DIAG>
-__device__ __forceinline__ void pairs_tile_body_v2(const BaDev& d, const int* __restrict__ blk_ptr, int nblk, int ti, int tj,
-                                                   int p_beg, int p_end, double* __restrict__ slab, double* __restrict__ tile) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nr = 7 * min(CB, d.V - ti * CB), nc = 7 * min(CB, d.V - tj * CB);      // used part of the tile
-  for (int t = tid; t < nr * TP2; t += PAIR_THREADS) tile[t] = 0.0;
-  __syncthreads();
-  const double* __restrict__ Z = d.Z;
-  const int* __restrict__ cam_idx = d.cam_idx;
-  const bool on = lane < 49;
-  const int li = on ? lane / 7 : 0, lj = on ? lane - 7 * (lane / 7) : 0;
-  double* tlane = tile + li * TP2 + lj;
-  // lanes 0..3 fetch bp[ti], bp[ti+1], bp[tj], bp[tj+1] of a point
-  auto fetch_bp = [&](int p) -> int {
-    if (p >= p_end) return 0;
-    const int which = lane & 3;
-    return blk_ptr[(size_t)p * (nblk + 1) + ((which & 2) ? tj : ti) + (which & 1)];
-  };
-  int p = p_beg + wave;
-  int bp1 = fetch_bp(p);
-  int bp2 = fetch_bp(p + PAIR_WAVES);
-  for (; p < p_end; p += PAIR_WAVES) {
-    const int bp3 = fetch_bp(p + 2 * PAIR_WAVES);          // block offsets two visits ahead
-    const int a0 = __builtin_amdgcn_readlane(bp1, 0), kA = __builtin_amdgcn_readlane(bp1, 1) - a0;
-    const int b0 = __builtin_amdgcn_readlane(bp1, 2), kB = __builtin_amdgcn_readlane(bp1, 3) - b0;
-    bp1 = bp2; bp2 = bp3;
-    if (kA <= 0 || kB <= 0) continue;
-    for (int ac = 0; ac < kA; ac += KMAX) {
-      const int na = min(KMAX, kA - ac);
-      for (int bc = 0; bc < (DIAG ? ac + 1 : kB); bc += KMAX) {      // diagonal tile: blocks with b <= a only
-        const int nb = min(KMAX, kB - bc);
-        // tile row offset of A observation l (lanes 0..5), tile column of B observation l (lanes 8..13)
-        int off = 0;
-        if (lane < na) off = 7 * TP2 * (cam_idx[a0 + ac + lane] - ti * CB);
-        else if (lane >= 8 && lane < 8 + nb) off = 7 * (cam_idx[b0 + bc + lane - 8] - tj * CB);
-        double za[KMAX][3], zb[KMAX][3];
-#pragma unroll
-        for (int a = 0; a < KMAX; ++a) {
-          if (a < na) {                                     // wave-uniform
-            const double* q = Z + (size_t)(a0 + ac + a) * 21 + 3 * li;
-            za[a][0] = q[0]; za[a][1] = q[1]; za[a][2] = q[2];
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < KMAX; ++b) {
-          if (b < nb) {
-            const double* q = Z + (size_t)(b0 + bc + b) * 21 + 3 * lj;
-            zb[b][0] = q[0]; zb[b][1] = q[1]; zb[b][2] = q[2];
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < KMAX; ++a) {
-          if (a < na) {
-            double* trow = tlane + __builtin_amdgcn_readlane(off, a);
-#pragma unroll
-            for (int b = 0; b < KMAX; ++b) {
-              if (b < nb && (!DIAG || bc + b <= ac + a)) {
-                const double val = za[a][0] * zb[b][0] + za[a][1] * zb[b][1] + za[a][2] * zb[b][2];
-                if (on) atomicAdd(trow + __builtin_amdgcn_readlane(off, 8 + b), val);
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int t = tid; t < nr * nc; t += PAIR_THREADS) {        // ba_schur_reduce never reads beyond the last camera
-    const int r = t / nc, c = t - r * nc;
-    slab[r * RB + c] = tile[r * TP2 + c];
-  }
-}
-
 __global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, const int* __restrict__ blk_ptr,
                                                                      double* __restrict__ ws, SchurPlan plan) {
   extern __shared__ double lds_pairs[];
@@ -517,13 +429,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void ba_schur_pairs_kernel(BaDev d, c
   const SchurTileRef t = plan_locate(plan, w);
   const int p_beg = t.chunk * plan.rpc[t.cls];
   const int p_end = min(d.N, p_beg + plan.rpc[t.cls]);
-  if (d.debug & 64) {          // the row-lane form, kept for A/B runs
-    if (t.ti != t.tj) pairs_tile_body<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
-    else pairs_tile_body<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
-    return;
-  }
-  if (t.ti != t.tj) pairs_tile_body_v2<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
-  else pairs_tile_body_v2<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
+  if (t.ti != t.tj) pairs_tile_body<false>(d, blk_ptr, plan.nblk, t.ti, t.tj, p_beg, p_end, slab, tile);
+  else pairs_tile_body<true>(d, blk_ptr, plan.nblk, t.ti, t.ti, p_beg, p_end, slab, tile);
 }
 
 __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, double* __restrict__ ws, SchurPlan plan) {
@@ -714,46 +621,73 @@ int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
   return SFM_OK;
 }
 
-bool ba_schur_uses_mfma(const sfm_ba_problem* p) {
-  if (!p->schur_mfma_ok) return false;
-  if (p->deterministic) return true;        // the sparse product accumulates with unordered LDS atomics
-  if (p->schur_mode == SFM_SCHUR_MFMA) return true;
-  if (p->schur_mode == SFM_SCHUR_PAIRS) return false;
+// Which product kernel the next iteration launches: SFM_SCHUR_MFMA (dense), SFM_SCHUR_ROWS (sparse, row panels) or
+// SFM_SCHUR_PAIRS (sparse, 18-camera tiles).  AUTO compares three cost models fitted on MI355X (profiles/r2n):
+//   dense   ~29 T MAC/s of its (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs + 15 us
+//   tiles   ~0.5 ns per (point, tile) visit + ~0.7 ps per LDS add + 10 us    (C4 share: 975 k visits, 285 M adds -> 0.63 ms)
+//   rows    ~50 ps per camera pair + ~50 ps per observation + 18 us          (C4 share: 5.8 M pairs -> 0.33 ms; C3: 0.43 ms;
+//           a 6 x 1260 scene: 26 us against the tiles' 17)
+int ba_schur_choice(const sfm_ba_problem* p) {
   const BaDev& d = p->dev;
-  if (d.N == 0 || d.M == 0) return false;
-  // Cost models fitted on MI355X (profiles/r02i): the dense SYRK retires ~29 T MAC/s of its
-  // (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs; the sparse kernel costs ~0.5 ns per
-  // (point, tile) visit plus ~0.7 ps per LDS add (C3: 120 k visits, 456 M adds -> 0.38 ms; a 12.5 k-point
-  // 200-camera shard at 15 %: 975 k visits, 285 M adds -> 0.65 ms against 1.58 ms dense).
+  if (p->deterministic && p->schur_mfma_ok) return SFM_SCHUR_MFMA;       // the sparse products accumulate with unordered LDS atomics
+  const bool rows_possible = !(p->debug & 128) && (size_t)7 * (((7 * d.V + 1) / 2) * 2) * sizeof(double) <= ((size_t)156 << 10) &&
+                             !(p->rows_built && !p->rows_ok);
+  if (p->schur_mode == SFM_SCHUR_MFMA && p->schur_mfma_ok) return SFM_SCHUR_MFMA;
+  if (p->schur_mode == SFM_SCHUR_PAIRS) return SFM_SCHUR_PAIRS;
+  if (p->schur_mode == SFM_SCHUR_ROWS) return rows_possible ? SFM_SCHUR_ROWS : SFM_SCHUR_PAIRS;
+  if (d.N == 0 || d.M == 0) return SFM_SCHUR_PAIRS;
   const double nblk = (double)((d.V + CB - 1) / CB);
   const double kbar = (double)d.M / d.N;
   const double dense_s = (0.5 * nblk * (nblk - 1) * 64.0 + nblk * 36.0) * 256.0 * 3.0 * d.N / 29e12 + 15e-6;
   const double nocc = nblk * (1.0 - std::pow(1.0 - 1.0 / nblk, kbar));            // occupied blocks per point
   const double visits = 0.5 * nocc * (nocc + 1.0) * d.N;
-  const double adds = 49.0 * 0.5 * kbar * (kbar + 1) * d.N;
-  const double sparse_s = visits * 0.5e-9 + adds * 0.7e-12 + 10e-6;
-  return dense_s < sparse_s;
+  const double pairs = 0.5 * kbar * (kbar + 1) * d.N;
+  const double tiles_s = visits * 0.5e-9 + 49.0 * pairs * 0.7e-12 + 10e-6;
+  const double rows_s = rows_possible ? 50e-12 * pairs + 50e-12 * (double)d.M + 18e-6 : 1e30;
+  const double mfma_s = p->schur_mfma_ok ? dense_s : 1e30;
+  if (mfma_s <= tiles_s && mfma_s <= rows_s) return SFM_SCHUR_MFMA;
+  return rows_s < tiles_s ? SFM_SCHUR_ROWS : SFM_SCHUR_PAIRS;
 }
+
+bool ba_schur_uses_mfma(const sfm_ba_problem* p) { return ba_schur_choice(p) == SFM_SCHUR_MFMA; }
 
 int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   if (d.N == 0 || d.M == 0) return SFM_OK;
   double* ws = static_cast<double*>(p->schur_ws);
   SchurPlan pl;
-  if (ba_schur_uses_mfma(p)) {
+  int choice = ba_schur_choice(p);
+  if (choice == SFM_SCHUR_ROWS) {            // camera-major list and work split on first use (blocking once)
+    if (!p->rows_built) {
+      SFM_TRY(ba_rows_enqueue_build(p));
+      SFM_TRY(ba_rows_plan(p));
+      p->rows_built = true;
+    }
+    if (!p->rows_ok) choice = SFM_SCHUR_PAIRS;
+  }
+  if (choice == SFM_SCHUR_MFMA) {
     pl = make_plan(d);
     pl.dbg = p->debug;
     const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);
     ba_schur_mfma_kernel<<<wgs, SCHUR_THREADS, kSchurLdsBytes, s>>>(d, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
+  } else if (choice == SFM_SCHUR_ROWS) {
+    // row-panel sparse product; its own reduce, then the camera accumulators / cost below
+    SFM_TRY(ba_rows_enqueue(p, s));
+    pl = make_pairs_plan(d);
+    const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
+    ba_schur_reduce_kernel<<<dim3(cam_blocks + 1, 4), 256, 0, s>>>(d, ws, pl, 0, p->lin_rows, p->lin_grid);
+    ba_tick(p, SFM_K_REDUCE, false, s);
+    SFM_HIP(hipGetLastError());
+    return SFM_OK;
   } else {
     pl = make_pairs_plan(d);
     const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);
     // a scene with fewer than 18 cameras uses only part of the tile: a smaller LDS footprint lets several
     // workgroups share a CU (small scenes are latency-bound)
-    const size_t lds = sizeof(double) * (size_t)7 * std::min(CB, d.V) * TP2;
+    const size_t lds = sizeof(double) * (size_t)7 * std::min(CB, d.V) * TP;
     ba_schur_pairs_kernel<<<wgs, PAIR_THREADS, lds, s>>>(d, p->schur_blk_ptr, ws, pl);
     ba_tick(p, SFM_K_SCHUR, false, s);
   }

@@ -174,10 +174,10 @@ def test_ba_residual_jacobian_golden(hip, name):
 
 
 @pytest.mark.parametrize("name", ["3x50", "5x200v80", "6x120v60"])
-@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+@pytest.mark.parametrize("mode", ["pairs", "mfma", "rows"])
 def test_ba_reduced_system_golden(hip, name, mode):
     g = load_golden("g6_ba_%s.npz" % name)
-    mode_id = hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA
+    mode_id = {"pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "rows": hip.SCHUR_ROWS}[mode]
     s, rhs = hip.ba_reduced_system(g["cams_init"].shape[0], g["pt_ptr"], g["cam_idx"], uv_norm_of(g),
                                    g["cams_init"], g["pts_init"], 5.0, schur_mode=mode_id)
     assert rel(s, g["lin_S"]) < 1e-11
@@ -186,13 +186,13 @@ def test_ba_reduced_system_golden(hip, name, mode):
 
 
 @pytest.mark.parametrize("name", BA_CASES)
-@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+@pytest.mark.parametrize("mode", ["pairs", "mfma", "rows"])
 def test_ba_iterations_golden(hip, name, mode):
     """1, 2 and 3 iterations against the reference's own results."""
     g = load_golden("g6_ba_%s.npz" % name)
     uvn = uv_norm_of(g)
     with hip.BaProblem(g["cams_init"].shape[0], g["pt_ptr"], g["cam_idx"], uvn) as prob:
-        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_option(hip.OPT_SCHUR, {"pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "rows": hip.SCHUR_ROWS}[mode])
         prob.set_state(g["cams_init"], g["pts_init"])
         for it in (1, 2, 3):
             prob.iterate(5.0, 1)
@@ -213,13 +213,13 @@ def test_ba_config2_reference_golden(hip, sfm):
     assert abs(rm - float(g["rmse_it3"])) / float(g["rmse_it3"]) < 1e-9
 
 
-@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+@pytest.mark.parametrize("mode", ["pairs", "mfma", "rows"])
 def test_ba_vs_oracle_midsize_ragged(hip, oracle, sfm, mode):
     """20 cams x 3000 points at 30 % visibility: ragged tracks (2..~12), some longer than the lane group."""
     sc = sfm.scenes.make_scene(20, 3001, 0.3, seed=8)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
-        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_option(hip.OPT_SCHUR, {"pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "rows": hip.SCHUR_ROWS}[mode])
         prob.set_state(sc.cams_init, sc.pts_init)
         prob.iterate(5.0, 3)
         cams, pts = prob.get_state()
@@ -240,9 +240,10 @@ def test_ba_config3_full_size_vs_oracle(hip, oracle, sfm):
     trace = []
     oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3, trace=trace)
     results = {}
-    for mode in (hip.SCHUR_MFMA, hip.SCHUR_PAIRS):
+    for mode in (hip.SCHUR_MFMA, hip.SCHUR_PAIRS, hip.SCHUR_ROWS):
         with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
             prob.set_option(hip.OPT_SCHUR, mode)
+            assert prob.info(hip.INFO_SCHUR_KERNEL) == mode
             prob.set_state(sc.cams_init, sc.pts_init)
             rm = [sfm.scenes.reprojection_rmse(sc.cams_init, sc.pts_init, sc)]
             for it in range(3):
@@ -257,19 +258,21 @@ def test_ba_config3_full_size_vs_oracle(hip, oracle, sfm):
             results[mode] = (c, p)
     assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_PAIRS][0]) < TOL
     assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_PAIRS][1]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_ROWS][0]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_ROWS][1]) < TOL
 
 
 # ---- BASELINE config 4: 200 cameras x 100 000 points @ 15 %, point blocks sharded over 8 GPUs ------------
 def test_ba_config4_one_gpu_share_vs_oracle(hip, oracle, sfm):
     """One GPU's share of config 4 (200 cameras x 12 500 points @ 15 %, seed 0): 1, 2 and 3 iterations against the
-    block-sparse oracle, with the kernel AUTO picks at this size (the sparse LDS-tile product) and with the dense
-    MFMA product forced.  Covers the 44-step Cholesky, the big back substitution (7V = 1400 > 416) and the
+    block-sparse oracle, with the kernel AUTO picks at this size (the sparse row-panel product), with the 18-camera
+    tile product and with the dense MFMA product forced.  Covers the 44-step Cholesky, the big back substitution (7V = 1400 > 416) and the
     global-accumulator mode of ba_linearize at the size the 8-GPU configuration runs them."""
     sc = sfm.scenes.make_scene(200, 12500, 0.15, seed=0)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     trace = []
     oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3, trace=trace)
-    for mode in (hip.SCHUR_AUTO, hip.SCHUR_MFMA):
+    for mode in (hip.SCHUR_AUTO, hip.SCHUR_PAIRS, hip.SCHUR_MFMA):
         with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
             prob.set_option(hip.OPT_SCHUR, mode)
             prob.set_state(sc.cams_init, sc.pts_init)
@@ -278,7 +281,7 @@ def test_ba_config4_one_gpu_share_vs_oracle(hip, oracle, sfm):
                 c, p = prob.get_state()
                 assert rel(c, trace[it][0]) < TOL and rel(p, trace[it][1]) < TOL, (mode, it)
             if mode == hip.SCHUR_AUTO:
-                assert prob.info(hip.INFO_SCHUR_KERNEL) == hip.SCHUR_PAIRS
+                assert prob.info(hip.INFO_SCHUR_KERNEL) == hip.SCHUR_ROWS
     r3 = sfm.scenes.reprojection_rmse(c, p, sc)
     ro = sfm.scenes.reprojection_rmse(trace[2][0], trace[2][1], sc)
     assert abs(r3 - ro) / ro < 1e-9
@@ -292,7 +295,7 @@ def test_ba_config4_full_size_one_gpu(hip, oracle, sfm):
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 1)
     results = {}
-    for mode in (hip.SCHUR_PAIRS, hip.SCHUR_MFMA):
+    for mode in (hip.SCHUR_ROWS, hip.SCHUR_MFMA):
         with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
             prob.set_option(hip.OPT_SCHUR, mode)
             prob.set_state(sc.cams_init, sc.pts_init)
@@ -307,8 +310,8 @@ def test_ba_config4_full_size_one_gpu(hip, oracle, sfm):
             assert all(b < a for a, b in zip(rm, rm[1:])), rm
             assert np.allclose(np.linalg.norm(c[:, 3:7], axis=1), 1.0, atol=1e-14)
             results[mode] = (c, p)
-    assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_PAIRS][0]) < TOL
-    assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_PAIRS][1]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][0], results[hip.SCHUR_ROWS][0]) < TOL
+    assert rel(results[hip.SCHUR_MFMA][1], results[hip.SCHUR_ROWS][1]) < TOL
 
 
 def test_ba_edge_cases(hip, oracle, sfm):
@@ -469,7 +472,7 @@ def test_processors_drop_in(hip, sfm, oracle, capsys):
 
 # ---- paths the headline config does not touch --------------------------------------------------------
 @pytest.mark.parametrize("n_cams", [160, 240])
-@pytest.mark.parametrize("mode", ["pairs", "mfma"])
+@pytest.mark.parametrize("mode", ["pairs", "mfma", "rows"])
 def test_ba_many_cameras_global_accumulator_path(hip, oracle, sfm, mode, n_cams):
     """160 cameras: cameras + accumulators exceed the 64 KB LDS budget of ba_linearize, so only the
     accumulators stay in LDS (mode 1) and ba_backsub reads cameras from global memory; 240 cameras: not
@@ -478,7 +481,7 @@ def test_ba_many_cameras_global_accumulator_path(hip, oracle, sfm, mode, n_cams)
     sc = sfm.scenes.make_scene(n_cams, 600, 0.08, seed=31)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
-        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_PAIRS if mode == "pairs" else hip.SCHUR_MFMA)
+        prob.set_option(hip.OPT_SCHUR, {"pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "rows": hip.SCHUR_ROWS}[mode])
         prob.set_state(sc.cams_init, sc.pts_init)
         prob.iterate(5.0, 2)
         cams, pts = prob.get_state()
