@@ -238,6 +238,7 @@ def main():
     # profiles/traffic.json = {"<workload key>": {"<kernel>": bytes, ...}}; null when no record matches this run
     workload_key = "%s/%dcams_%dpts_per_rank/%s" % (args.config, scene.n_cams, int(ptr_l.shape[0]) - 1, schur_kernel)
     roofline["traffic"] = None
+    roofline["traffic_key"] = workload_key
     tfile = os.path.join(REPO, "profiles", "traffic.json")
     traffic_rec = None
     if os.path.exists(tfile):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# One gpurun call = GPU tests + smoke + bench + rocprofv3 kernel stats (each call pays ~10 min of
-# box acquisition, so everything rides in one).  Usage (from the repo root on the GPU box):
+# One gpurun call = GPU tests + smoke + benches + rocprofv3 kernel stats + PMC traffic passes (every call pays minutes
+# of box acquisition, so everything rides in one).  Usage (from the repo root on the GPU box):
 #   bash tools/gpu_round.sh [tag]
-# Stops at the first step that is killed/timed out (rc >= 124); ordinary test failures do not stop it.
-tag=${1:-r01}
+# Stops at the first step that is killed / timed out (rc >= 124); ordinary test failures do not stop it.
+tag=${1:-r2}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -16,27 +16,32 @@ step() {   # step <seconds> <logfile> <cmd...>
   if [ $rc -ge 124 ]; then echo "step killed; stopping" | tee -a "$out/steps.log"; exit $rc; fi
   return 0
 }
-step 600 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 300
-tail -5 "$out/pytest_gpu.log"
+step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600
+tail -3 "$out/pytest_gpu.log"
 step 120 "$out/smoke.log" python __graft_entry__.py smoke
-tail -2 "$out/smoke.log"
-step 240 "$out/bench.log" python bench.py --steps 20 --warmup 3
-tail -1 "$out/bench.log"
+tail -1 "$out/smoke.log"
+step 300 "$out/bench.log" python bench.py --steps 20 --warmup 3
+tail -c 400 "$out/bench.log"
+step 240 "$out/bench_c4_share.log" python bench.py --config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline
+step 240 "$out/bench_c4_full.log" python bench.py --config C4 --steps 5 --warmup 1 --no-cpu-baseline
 step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
-tail -1 "$out/bench_tri_pnp.log"
-step 240 "$out/bench_pairs.log" python bench.py --steps 5 --warmup 1 --schur pairs --no-cpu-baseline
-tail -1 "$out/bench_pairs.log"
-step 120 "$out/probe_schur.log" python tools/probe_schur.py
-tail -1 "$out/probe_schur.log"
-step 300 "$out/rocprof.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline
-find "$out/prof" -name "*kernel_stats*" | head -3
-f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -14 "$f"
-# HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), no other trace domains
-step 300 "$out/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
-step 300 "$out/pmc_write.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
-python3 tools/parse_pmc.py "$out/pmc_fetch" "$out/pmc_write" "$out/traffic.json"
-# matrix-pipe / LDS counters of every kernel (own pass, SQ block)
+step 120 "$out/probe_solve.log" python tools/probe_solve.py
+step 120 "$out/time_schur.log" python tools/time_schur.py
+step 60 "$out/microbench_solve.txt" tools/bin/microbench_solve
+step 60 "$out/microbench_elim.txt" tools/bin/microbench_elim
+for cfg in c3 c4share; do
+  if [ $cfg = c3 ]; then args="--steps 20 --warmup 3 --no-cpu-baseline"; else args="--config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline"; fi
+  step 300 "$out/rocprof_$cfg.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$cfg" -- python3 bench.py $args
+  f=$(find "$out/prof_$cfg" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$out/kernel_stats_$cfg.csv" && head -12 "$f"
+  # HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), no other trace domains
+  step 300 "$out/pmc_fetch_$cfg.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$cfg" -- python3 bench.py ${args/--steps 20/--steps 5}
+  step 300 "$out/pmc_write_$cfg.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$cfg" -- python3 bench.py ${args/--steps 20/--steps 5}
+  if [ $cfg = c3 ]; then blog="$out/bench.log"; else blog="$out/bench_c4_share.log"; fi
+  key=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['roofline']['traffic_key'])" "$blog")
+  python3 tools/parse_pmc.py "$out/pmc_fetch_$cfg" "$out/pmc_write_$cfg" "$out/traffic.json" "$key"
+done
+# matrix-pipe / LDS counters of every kernel (own pass, SQ block), C3
 step 300 "$out/pmc_sq.log" rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
 python3 - "$out/pmc_sq" "$out/pmc_sq_summary.csv" <<'PYEOF'
 import csv, glob, os, sys, collections
