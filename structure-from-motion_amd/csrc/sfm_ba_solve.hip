@@ -456,7 +456,8 @@ __global__ __launch_bounds__(BS_THREADS) void ba_back_solve_kernel(BaDev d, int 
 }
 
 // y[32 bi ..] -= sum_{r = g0}^{g1 - 1} L[r][bi]^T x_r for block column bi = blockIdx.x < g0 (x in d.delta).
-// Thread (slice, q): block rows r = g0 + slice, + 16, ...; the column pair q of every one of them.
+// Thread (slice, q): block rows r = g0 + 16 blockIdx.y + slice, + 16 gridDim.y, ...; the column pair q of every one
+// of them.  blockIdx.y spreads a block column over several workgroups (one f64 atomic per output and workgroup).
 __global__ __launch_bounds__(256) void ba_back_update_kernel(BaDev d, int g0, int g1) {
   __shared__ double part[16][NB + 1];
   const int bi = blockIdx.x;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void ba_back_update_kernel(BaDev d, int g0, in
   const int ucol = (uq & 3) + 8 * (uq >> 2);
   const int uoff = (uq >> 2) * 256 + (uq & 3) * 64;
   double s0 = 0, s1 = 0;
-  for (int r = g0 + slice; r < g1; r += 16) {
+  for (int r = g0 + 16 * blockIdx.y + slice; r < g1; r += 16 * gridDim.y) {
     const double* blk = d.red + red_blk_base(r, bi) + uoff;
     const double* x = d.delta + r * NB;
     f64x2 w[NB];
@@ -480,7 +481,8 @@ __global__ __launch_bounds__(256) void ba_back_update_kernel(BaDev d, int g0, in
     double s = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += part[q][tid];
-    d.red[red_rhs_off(d.nbk) + bi * NB + tid] -= s;
+    if (gridDim.y == 1) d.red[red_rhs_off(d.nbk) + bi * NB + tid] -= s;
+    else if (s != 0.0) atomicAdd(&d.red[red_rhs_off(d.nbk) + bi * NB + tid], -s);
   }
 }
 
@@ -505,12 +507,18 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   }
   // back substitution in groups of at most 28 block rows, from the bottom; between two groups one multi-workgroup
   // launch folds the finished group into everything above it
-  const int ngroups = (nbk + BS_ROWS - 1) / BS_ROWS;
+  // (one workgroup streams a group's L blocks at one CU's bandwidth, ~100 GB/s: groups of 11-14 block rows keep a block
+  // step near its latency floor; up to 28 block rows -- V <= 128 -- stay one group and one launch)
+  const int gmax = nbk <= BS_ROWS ? BS_ROWS : 12;
+  const int ngroups = (nbk + gmax - 1) / gmax;
   const int gsize = (nbk + ngroups - 1) / ngroups;
   for (int hi = nbk; hi > 0;) {
     const int lo = std::max(0, hi - gsize);
     ba_back_solve_kernel<<<1, BS_THREADS, 0, s>>>(d, p->cur, hi, lo);
-    if (lo > 0) ba_back_update_kernel<<<lo, 256, 0, s>>>(d, lo, hi);
+    if (lo > 0) {
+      const int slices = (p->deterministic || hi - lo <= 16) ? 1 : std::min(4, (hi - lo + 15) / 16 + 1);
+      ba_back_update_kernel<<<dim3(lo, slices), 256, 0, s>>>(d, lo, hi);
+    }
     hi = lo;
   }
   SFM_HIP(hipGetLastError());
