@@ -334,9 +334,13 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         # PCIe-inclusive rate of the host-buffer entry point (sfm_ba_solve: create + upload + 3 iterations +
         # download), for DESIGN.md; never used as `value`
-        t0 = time.perf_counter()
-        native.ba_solve(scene.n_cams, scene.pt_ptr, scene.cam_idx, uvn, scene.cams_init, scene.pts_init, LAMBDA, 3)
-        out["host_buffer_path"] = {"seconds_for_3_iterations_incl_setup_and_pcie": time.perf_counter() - t0}
+        # (three calls: the first one follows ~10 s of CPU-only work, i.e. an idle GPU and a cold allocation pool)
+        hb = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            native.ba_solve(scene.n_cams, scene.pt_ptr, scene.cam_idx, uvn, scene.cams_init, scene.pts_init, LAMBDA, 3)
+            hb.append(time.perf_counter() - t0)
+        out["host_buffer_path"] = {"seconds_for_3_iterations_incl_setup_and_pcie": min(hb), "first_call_after_idle": hb[0]}
         out["drop_in_path"] = drop_in_path(sfm, scene)
 
     if world > 1 or args.no_cpu_baseline:

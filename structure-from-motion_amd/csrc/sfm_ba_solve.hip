@@ -494,10 +494,182 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ red, int P, doub
   out[idx] = red[red_index(max(i, j), min(i, j))] + (i == j ? lambda : 0.0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small systems (P <= 64: the nine cameras or fewer of the reference's usual scenes): the whole reduced solve --
+// factorisation, forward and back substitution, camera update -- in ONE single-workgroup launch.
+//
+// The multi-wave elimination of chol_trsm_cols taken over the whole matrix: lane = row (all P rows at once, no block
+// steps), wave w < 8 owns columns 8w .. 8w+7, two columns per step with the 2x2 pivot recurrence above.  The wave
+// that owns the current pair (the chain, raised priority: it shares its SIMD with another wave) publishes
+// (x, y) = (L[row][j], L[row][j+1]) of every row to LDS; later waves fold it into their columns.  The published
+// values ARE L (xy[s][row] = L[row][2s .. 2s+1]) and stay in LDS for the back substitution.
+// The right-hand side is one more COLUMN, owned by wave 8: it follows the published steps with the forward
+// substitution y_j = b_j / l11, y_j+1 = (b_j+1 - l21 y_j) / l22, b_row -= x y_j + y y_j+1 -- off the chain's critical
+// path, no 65th row.
+// Back substitution: one wave, lane = row, last pair first; row j of L is read from LDS across the lanes (leading
+// dimension 65 so that the column walk touches every bank twice, not thirty-two times), two steps ahead of its use.
+// No block boundary, no global round trip for L, no second launch.  Measured (tools/time_small.py, tools/stamps_small.py):
+// 6 cameras (P = 42) 33.1 us per iteration against 37.3 with block steps; 9 cameras (P = 63) 45.5 against 44.9 -- the
+// serial pair-steps (~680 cycles each here, hand-overs included) catch up with the two block steps that run their
+// rows on separate CUs, so the kernel is used up to P = 56 (eight cameras).
+constexpr int SM_SEG = 8;                        // columns per wave
+constexpr int SM_COLWAVES = 8;
+constexpr int SM_THREADS = 64 * (SM_COLWAVES + 1), SM_STEPS = 32, SM_LD = 65;
+constexpr int kSmallMaxP = 64;                 // what the kernel can hold
+constexpr int kSmallUseP = 56;                 // what it is used for
+
+__global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int cur, double lambda) {
+  __shared__ f64x2 xy[SM_STEPS][SM_LD];      // [pair-step][row] = (L[row][2s], L[row][2s+1])
+  __shared__ f64x4 piv[SM_STEPS];            // (1/l11, l21, 1/l22, -) of the pair's 2x2 pivot
+  __shared__ f64x2 ysol[SM_STEPS];           // y = L^-1 rhs, two entries per pair-step
+  __shared__ double dp[kSmallMaxP];          // the solution, for the camera update
+  __shared__ int flag;                       // pair-steps published
+  const int P = d.P;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Pe = (P + 1) & ~1, S = Pe >> 1;  // an odd P gets one identity row / column
+  const int nseg = (Pe + SM_SEG - 1) / SM_SEG;
+  const double* __restrict__ red = d.red;
+  const double* __restrict__ rhs = d.red + red_rhs_off(d.nbk);
+  if (tid == 0) flag = 0;
+  // diagnostic stamps (SFM_OPT_DEBUG bit 8): [0] start, [1] loaded, [2] factorised, [3] back-substituted, [4] end,
+  // [8 + w] wave w takes the chain over
+  unsigned long long* stamp = (d.stamps && lane == 0) ? d.stamps : nullptr;
+  if (stamp && wave == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+  double c[SM_SEG], b = 0.0;
+  if (wave < nseg) {
+#pragma unroll
+    for (int u = 0; u < SM_SEG; ++u) {
+      const int col = SM_SEG * wave + u;
+      double v = (lane < P && col <= lane) ? red[red_index(lane, col)] : 0.0;      // lower part; the upper is never used
+      if (col == lane) v = lane < P ? v + lambda : 1.0;
+      c[u] = v;
+    }
+  } else if (wave == SM_COLWAVES) {
+    b = lane < P ? rhs[lane] : 0.0;
+  }
+  // the camera update's operands, long before they are needed
+  const int cam_i = SM_THREADS - 1 - tid;
+  double cam[7];
+  if (cam_i < d.V) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * cam_i + k];
+  }
+  __syncthreads();
+  if (stamp && wave == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+  if (wave == SM_COLWAVES) {
+    for (int s = 0; s < S; ++s) {
+      while (__hip_atomic_load(&flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const f64x4 pv = piv[s];
+      const f64x2 own = xy[s][lane];
+      const double bj = lane_bcast(b, 2 * s), bj1 = lane_bcast(b, 2 * s + 1);
+      const double yj = bj * pv.x, yj1 = (bj1 - pv.y * yj) * pv.z;
+      b = __builtin_fma(-own.y, yj1, __builtin_fma(-own.x, yj, b));
+      if (lane == 0) ysol[s] = f64x2{yj, yj1};
+    }
+  } else {
+    for (int seg = 0; seg < nseg; ++seg) {
+      if (wave == seg) {
+        if (stamp) stamp[8 + seg] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int t = 0; t < SM_SEG / 2; ++t) {
+          const int j = 2 * t, s = (SM_SEG / 2) * seg + t, l0 = SM_SEG * seg + j;       // l0: the lane (= row) of column l0
+          if (s >= S) break;
+          const double pa = lane_bcast(c[j], l0), pb = lane_bcast(c[j], l0 + 1), pc = lane_bcast(c[j + 1], l0 + 1);
+          const double det = __builtin_fma(pa, pc, -(pb * pb));
+          const double r1 = rsqrt_nr(pa), r2 = rsqrt_nr(det);
+          const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
+          const double x = c[j] * r1;
+          const double y = (c[j + 1] - x * l21) * i22;
+          c[j] = x; c[j + 1] = y;
+          xy[s][lane] = f64x2{x, y};
+          if (lane == 0) piv[s] = f64x4{r1, l21, i22, 0.0};
+          if (t < SM_SEG / 2 - 1) {
+            const double x2 = lane_bcast(x, l0 + 2), y2 = lane_bcast(y, l0 + 2);
+            const double x3 = lane_bcast(x, l0 + 3), y3 = lane_bcast(y, l0 + 3);
+            c[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, c[j + 2]));
+            c[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, c[j + 3]));
+#pragma unroll
+            for (int u = j + 4; u < SM_SEG; ++u) { const f64x2 q = xy[s][SM_SEG * seg + u]; c[u] = __builtin_fma(-y, q.y, __builtin_fma(-x, q.x, c[u])); }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_store(&flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      } else if (wave > seg && wave < nseg) {
+#pragma unroll
+        for (int t = 0; t < SM_SEG / 2; ++t) {
+          const int s = (SM_SEG / 2) * seg + t;
+          if (s >= S) break;
+          while (__hip_atomic_load(&flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const f64x2 own = xy[s][lane];
+#pragma unroll
+          for (int u = 0; u < SM_SEG; ++u) { const f64x2 q = xy[s][SM_SEG * wave + u]; c[u] = __builtin_fma(-own.y, q.y, __builtin_fma(-own.x, q.x, c[u])); }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (stamp && wave == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+  if (wave == 0) {
+    // L^T dp = y, pair by pair from the bottom: lane i carries y_i until its pair is solved, dp_i afterwards.
+    // Step operands (the pivot and L[j][lane], L[j+1][lane], used by lanes < j only) are loaded two steps ahead.
+    double v = 0.0;
+    if (lane < Pe) { const f64x2 t = ysol[lane >> 1]; v = (lane & 1) ? t.y : t.x; }
+    const double* lrow = reinterpret_cast<const double*>(&xy[lane >> 1][0]) + (lane & 1);    // L[.][lane]
+    auto step = [&](int s, const f64x4& pv, double a0, double a1) {
+      const int j = 2 * s;
+      const double yj = lane_bcast(v, j), yj1 = lane_bcast(v, j + 1);
+      const double x1 = yj1 * pv.z;
+      const double x0 = (yj - pv.y * x1) * pv.x;
+      const double upd = __builtin_fma(-a1, x1, __builtin_fma(-a0, x0, v));
+      v = lane < j ? upd : (lane == j ? x0 : (lane == j + 1 ? x1 : v));
+    };
+    int sa = S - 1, sb = S > 1 ? S - 2 : 0;
+    f64x4 pvA = piv[sa], pvB = piv[sb];
+    double aA0 = lrow[4 * sa], aA1 = lrow[4 * sa + 2], aB0 = lrow[4 * sb], aB1 = lrow[4 * sb + 2];
+    for (int s = S - 1; s >= 0; s -= 2) {
+      const int na = s >= 2 ? s - 2 : 0, nb = s >= 3 ? s - 3 : 0;
+      const f64x4 pvA2 = piv[na];
+      const double nA0 = lrow[4 * na], nA1 = lrow[4 * na + 2];
+      step(s, pvA, aA0, aA1);
+      const f64x4 pvB2 = piv[nb];
+      const double nB0 = lrow[4 * nb], nB1 = lrow[4 * nb + 2];
+      if (s >= 1) step(s - 1, pvB, aB0, aB1);
+      pvA = pvA2; aA0 = nA0; aA1 = nA1; pvB = pvB2; aB0 = nB0; aB1 = nB1;
+    }
+    if (lane < P) { d.delta[lane] = v; dp[lane] = v; }
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+  }
+  __syncthreads();
+  if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
+  if (cam_i < d.V) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) cam[k] += dp[7 * cam_i + k];                                  // ba:383
+    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
+#pragma unroll
+    for (int k = 3; k < 7; ++k) cam[k] /= nq;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d.cams[7 * cam_i + k] = cam[k];
+    CamPrep out;
+    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
+    d.prep[cur ^ 1][cam_i] = out;
+    report_status(d.status, st, cam_i);
+  }
+  if (stamp && wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[4] = __builtin_amdgcn_s_memtime(); }
+}
+
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   const int nbk = d.nbk;
+  if (d.P <= ((d.debug & 256) ? kSmallMaxP : kSmallUseP) && !(d.debug & 64)) {      // SFM_OPT_DEBUG bit 64: block steps for every size; 256: the small kernel up to P = 64
+    ba_small_solve_kernel<<<1, SM_THREADS, 0, s>>>(d, p->cur, lambda);
+    SFM_HIP(hipGetLastError());
+    return SFM_OK;
+  }
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
     // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns

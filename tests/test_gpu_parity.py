@@ -384,6 +384,26 @@ def test_ba_fused_and_separate_launches_agree(hip, sfm):
     assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-13
 
 
+@pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
+def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
+    """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;
+    bit 64 sends the same system through the block column steps.  Both against the oracle (odd and even P, P = 63 with
+    its identity padding row, the smallest scene)."""
+    sc = sfm.scenes.make_scene(n_cams, 700, 0.8, seed=70 + n_cams)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    out = []
+    for dbg in (256, 64):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            out.append(prob.get_state())
+    for cams, pts in out:
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+    assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
+
+
 def test_ba_split_phases_equal_iterate(hip, sfm):
     """linearize_reduce + solve_update (the multi-GPU split) == iterate on one rank."""
     sc = sfm.scenes.make_scene(7, 500, 0.5, seed=4)

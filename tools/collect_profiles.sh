@@ -10,6 +10,9 @@ done
 for f in bench bench_c4_share bench_c4_full bench_tri_pnp probe_solve time_schur; do
   [ -f "$src/$f.log" ] && grep -E '^\{|kernel us|^\[' "$src/$f.log" | tail -20 > "$dst/$f.json"
 done
+for f in time_small stamps_small; do
+  [ -f "$src/$f.log" ] && grep -v amdgpu.ids "$src/$f.log" > "$dst/$f.txt"
+done
 tail -3 "$src/pytest_gpu.log" > "$dst/pytest_gpu_tail.txt"
 tail -2 "$src/smoke.log" > "$dst/smoke_tail.txt"
 python3 - "$src/traffic.json" profiles/traffic.json <<'PY'

@@ -27,6 +27,8 @@ step 240 "$out/bench_c4_full.log" python bench.py --config C4 --steps 5 --warmup
 step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
 step 120 "$out/probe_solve.log" python tools/probe_solve.py
 step 120 "$out/time_schur.log" python tools/time_schur.py
+step 120 "$out/time_small.log" python tools/time_small.py
+step 60 "$out/stamps_small.log" python tools/stamps_small.py
 step 60 "$out/microbench_solve.txt" tools/bin/microbench_solve
 step 60 "$out/microbench_elim.txt" tools/bin/microbench_elim
 for cfg in c3 c4share; do

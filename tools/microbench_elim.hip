@@ -161,6 +161,118 @@ __global__ __launch_bounds__(64 * WAVES) void k_elim4(const double* in, double* 
   if (lane == 0) { cyc[3 * wave] = t1 - t0; cyc[3 * wave + 1] = tchain0 - t0; cyc[3 * wave + 2] = tchain1 - t0; }
 }
 
+// Variant 5: the consumer is software-pipelined (reads of step s issued before the FMAs of step s-1), the flag goes
+// up right after (x, y) are in LDS, the chain's far columns are folded one step late inside the reciprocal-square-root
+// latency, and at a hand-over the new chain wave updates only its first two columns before it starts (the other
+// columns' last consumer update becomes its first deferred update).
+template <int WAVES, int NR, int POLL_SLEEP, bool LATE>
+__global__ __launch_bounds__(64 * WAVES) void k_elim5(const double* in, double* out, unsigned long long* cyc) {
+  constexpr int CW = NB / WAVES, PS = CW / 2;
+  __shared__ __attribute__((aligned(16))) f64x2 xy[16][64];
+  __shared__ int flag_s;
+  int* flag = &flag_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double c[CW];
+#pragma unroll
+  for (int u = 0; u < CW; ++u) c[u] = in[lane * NB + CW * wave + u];
+  if (threadIdx.x == 0) *flag = 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long tchain0 = 0, tchain1 = 0;
+  // ---- consumer of every step before my segment
+  double xp = 0.0, yp = 0.0;
+  f64x2 q[CW];
+#pragma unroll
+  for (int u = 0; u < CW; ++u) q[u] = f64x2{0.0, 0.0};
+  const int nprev = PS * wave;
+  for (int s = 0; s < nprev; ++s) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) { if (POLL_SLEEP) __builtin_amdgcn_s_sleep(POLL_SLEEP); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const f64x2 own = xy[s][lane];
+    f64x2 qn[CW];
+#pragma unroll
+    for (int u = 0; u < CW; ++u) qn[u] = xy[s][CW * wave + u];
+#pragma unroll
+    for (int u = 0; u < CW; ++u) c[u] = __builtin_fma(-yp, q[u].y, __builtin_fma(-xp, q[u].x, c[u]));
+    xp = own.x; yp = own.y;
+#pragma unroll
+    for (int u = 0; u < CW; ++u) q[u] = qn[u];
+  }
+  // ---- chain: my first two columns get the pending update now, the others inside the first step
+  c[0] = __builtin_fma(-yp, q[0].y, __builtin_fma(-xp, q[0].x, c[0]));
+  c[1] = __builtin_fma(-yp, q[1].y, __builtin_fma(-xp, q[1].x, c[1]));
+  tchain0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int t = 0; t < PS; ++t) {
+    const int j = 2 * t, s = PS * wave + t, l0 = CW * wave + j;
+    const double pa = lane_bcast(c[j], l0), pb = lane_bcast(c[j], l0 + 1), pc = lane_bcast(c[j + 1], l0 + 1);
+    const double det = __builtin_fma(pa, pc, -(pb * pb));
+    const double r1 = rsqrt_n<NR>(pa), r2 = rsqrt_n<NR>(det);
+    const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
+#pragma unroll
+    for (int u = j + 2; u < CW; ++u) c[u] = __builtin_fma(-yp, q[u].y, __builtin_fma(-xp, q[u].x, c[u]));     // one step late
+    const double x = c[j] * r1;
+    const double y = (c[j + 1] - x * l21) * i22;
+    c[j] = x; c[j + 1] = y;
+    xy[s][lane] = f64x2{x, y};
+    if (LATE) {
+      // the LDS write drains behind the register broadcasts; the flag goes up after them
+      if (t < PS - 1) {
+        const double x2 = lane_bcast(x, l0 + 2), y2 = lane_bcast(y, l0 + 2);
+        const double x3 = lane_bcast(x, l0 + 3), y3 = lane_bcast(y, l0 + 3);
+        c[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, c[j + 2]));
+        c[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, c[j + 3]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (t < PS - 1) {
+#pragma unroll
+        for (int u = j + 4; u < CW; ++u) q[u] = xy[s][CW * wave + u];
+        xp = x; yp = y;
+      }
+    } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (t < PS - 1) {
+      const double x2 = lane_bcast(x, l0 + 2), y2 = lane_bcast(y, l0 + 2);
+      const double x3 = lane_bcast(x, l0 + 3), y3 = lane_bcast(y, l0 + 3);
+      c[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, c[j + 2]));
+      c[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, c[j + 3]));
+#pragma unroll
+      for (int u = j + 4; u < CW; ++u) q[u] = xy[s][CW * wave + u];
+      xp = x; yp = y;
+    }
+    }
+  }
+  tchain1 = __builtin_amdgcn_s_memtime();
+  double sum = 0;
+#pragma unroll
+  for (int u = 0; u < CW; ++u) sum += c[u];
+  asm volatile("" :: "v"(sum));
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[threadIdx.x] = sum;
+  if (lane == 0) { cyc[3 * wave] = t1 - t0; cyc[3 * wave + 1] = tchain0 - t0; cyc[3 * wave + 2] = tchain1 - t0; }
+}
+
+template <int WAVES, int NR, int POLL_SLEEP, bool LATE>
+int run5(const double* din, const char* name) {
+  unsigned long long* dc4; double* dout4;
+  CHECK(hipMalloc(&dc4, 3 * WAVES * 8)); CHECK(hipMalloc(&dout4, 64 * WAVES * sizeof(double)));
+  for (int rep = 0; rep < 3; ++rep) { k_elim5<WAVES, NR, POLL_SLEEP, LATE><<<1, 64 * WAVES>>>(din, dout4, dc4); CHECK(hipDeviceSynchronize()); }
+  unsigned long long c[24];
+  CHECK(hipMemcpy(c, dc4, 3 * WAVES * 8, hipMemcpyDeviceToHost));
+  std::vector<double> o(64 * WAVES);
+  CHECK(hipMemcpy(o.data(), dout4, o.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double chk = 0; for (double v : o) chk += v;
+  unsigned long long end = 0;
+  for (int w = 0; w < WAVES; ++w) end = c[3 * w] > end ? c[3 * w] : end;
+  printf("%-44s total %5llu | chain windows:", name, end);
+  for (int w = 0; w < WAVES; ++w) printf(" %llu-%llu", c[3 * w + 1], c[3 * w + 2]);
+  printf("  [check %.9f]\n", chk);
+  return 0;
+}
+
 template <int WAVES, int NR, int POLL_SLEEP, bool FMA2>
 int run4(const double* din, const char* name) {
   unsigned long long* dc4; double* dout4;
@@ -172,7 +284,10 @@ int run4(const double* din, const char* name) {
   for (int w = 0; w < WAVES; ++w) end = c[3 * w] > end ? c[3 * w] : end;
   printf("%-44s total %5llu | chain windows:", name, end);
   for (int w = 0; w < WAVES; ++w) printf(" %llu-%llu", c[3 * w + 1], c[3 * w + 2]);
-  printf("\n");
+  std::vector<double> o(64 * WAVES);
+  CHECK(hipMemcpy(o.data(), dout4, o.size() * sizeof(double), hipMemcpyDeviceToHost));
+  double chk = 0; for (double v : o) chk += v;
+  printf("  [check %.9f]\n", chk);
   return 0;
 }
 
@@ -212,5 +327,11 @@ int main() {
   run4<4, 1, 1, true>(din, "4 waves, 1 Newton, sleep 1, 2 FMAs");
   run4<8, 2, 1, true>(din, "8 waves, 2 Newton, sleep 1, 2 FMAs");
   run4<2, 2, 1, true>(din, "2 waves, 2 Newton, sleep 1, 2 FMAs");
+  run5<4, 2, 1, false>(din, "v5 pipelined: 4 waves, sleep 1");
+  run5<4, 2, 0, false>(din, "v5 pipelined: 4 waves, busy poll");
+  run5<4, 2, 1, true>(din, "v5 late flag: 4 waves, sleep 1");
+  run5<4, 2, 0, true>(din, "v5 late flag: 4 waves, busy poll");
+  run5<8, 2, 0, true>(din, "v5 late flag: 8 waves, busy poll");
+  run5<2, 2, 0, true>(din, "v5 late flag: 2 waves, busy poll");
   return 0;
 }
