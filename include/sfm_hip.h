@@ -65,6 +65,10 @@ extern "C" {
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
                                  * and V <= 234; slower (C3: see DESIGN.md). */
+#define SFM_OPT_GRAPH         5 /* 1: sfm_ba_iterate captures the steady-state iteration body (fused linearise, Schur product, reduce,
+                                 * reduced solve) as a hipGraph -- one per camera-slot parity -- and replays it for every iteration
+                                 * after the first; same kernels, same arguments, same results.  Off by default: on this stack the
+                                 * kernels of an iteration already run back to back from eager launches. */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
@@ -74,6 +78,7 @@ extern "C" {
 #define SFM_INFO_N_PTS         4
 #define SFM_INFO_N_OBS         5
 #define SFM_INFO_MAX_TRACK     6  /* longest track (observations of one point) */
+#define SFM_INFO_GRAPH_REPLAYS 7  /* iterations sfm_ba_iterate carried out as hipGraph replays (SFM_OPT_GRAPH) */
 
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */
 #define SFM_K_PREP       0

@@ -152,6 +152,14 @@ struct sfm_ba_problem {
   int* rows_first = nullptr;               // [groups+1] first workgroup of every camera group
   void* rows_ws = nullptr;                 // [rows_wgs][7 R][tpr] split-K panels
   int rows_R = 0, rows_tpr = 0, rows_wgs = 0, rows_groups = 0;
+  // SFM_OPT_GRAPH: the steady-state iteration body (fused linearise + Schur + reduce + solve) captured once per
+  // camera-slot parity and replayed by sfm_ba_iterate; dropped whenever an option, the stream, the reduced buffer or
+  // the structure changes
+  int use_graph = 0;
+  hipGraphExec_t body_graph[2] = {nullptr, nullptr};
+  double graph_lambda = 0;
+  int graph_quirks = 0;
+  long long graph_replays = 0;    // SFM_INFO_GRAPH_REPLAYS
   sfm::KernelTimer timers[SFM_K_COUNT];
 };
 
@@ -170,6 +178,7 @@ int ba_enqueue_prep(sfm_ba_problem* p);
 int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
 int ba_flush(sfm_ba_problem* p);      // complete a deferred back substitution
+void ba_graph_drop(sfm_ba_problem* p); // forget the captured iteration bodies
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
 bool ba_can_fuse(const sfm_ba_problem* p);
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras

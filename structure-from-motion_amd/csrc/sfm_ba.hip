@@ -542,10 +542,58 @@ int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks) {
   return enqueue_backsub(p, lambda, quirks);
 }
 
+void ba_graph_drop(sfm_ba_problem* p) {
+  for (auto& g : p->body_graph) {
+    if (g) (void)hipGraphExecDestroy(g);
+    g = nullptr;
+  }
+}
+
+// One steady-state iteration (the previous back substitution pending, so the linearisation is the fused kernel) as a
+// hipGraph: captured from the very enqueue functions the eager path uses -- which also advance the host-side state
+// exactly as an eager iteration does -- then launched once to carry that iteration out.
+static int capture_body(sfm_ba_problem* p, double lambda, int quirks) {
+  hipStream_t s = p->stream;
+  const int slot = p->cur;
+  SFM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+  int st = ba_enqueue_linearize_reduce(p, lambda, quirks);
+  if (st == SFM_OK) st = ba_enqueue_solve_update(p, lambda, quirks);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (st != SFM_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+  SFM_HIP(e);
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  SFM_HIP(ei);
+  p->body_graph[slot] = exec;
+  SFM_HIP(hipGraphLaunch(exec, s));
+  return SFM_OK;
+}
+
 // `iters` complete iterations: between two of them the back substitution rides in the next linearisation's launch,
-// the last one is flushed before returning.
+// the last one is flushed before returning.  With SFM_OPT_GRAPH the iterations after the first are graph replays
+// (two graphs: the camera slots alternate).
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks) {
+  const bool graphs = p->use_graph && p->timing == 0 && p->stream != nullptr && ba_can_fuse(p);
+  if (graphs && (lambda != p->graph_lambda || quirks != p->graph_quirks)) {
+    ba_graph_drop(p);
+    p->graph_lambda = lambda;
+    p->graph_quirks = quirks;
+  }
   for (int it = 0; it < iters; ++it) {
+    const bool steady = p->backsub_pending && lambda == p->pending_lambda && quirks == p->pending_quirks;
+    if (graphs && steady) {
+      if (p->body_graph[p->cur] == nullptr) {
+        SFM_TRY(capture_body(p, lambda, quirks));
+      } else {
+        SFM_HIP(hipGraphLaunch(p->body_graph[p->cur], p->stream));
+        p->cur ^= 1;              // what the captured enqueue calls did to the host-side state: the fused launch
+        p->red_clean = false;     // switched the camera slot; the back substitution is pending again
+        ++p->graph_replays;
+      }
+      continue;
+    }
     SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
     SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
   }

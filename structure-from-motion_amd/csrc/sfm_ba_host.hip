@@ -273,6 +273,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (p == nullptr) return SFM_OK;
   if (p->magic != kBaMagic) { set_error("sfm_ba_destroy: invalid handle"); return SFM_E_HANDLE; }
   if (ctx().inited && p->stream) (void)hipStreamSynchronize(p->stream);
+  ba_graph_drop(p);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
                   d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
@@ -289,13 +290,18 @@ int sfm_ba_set_stream(sfm_ba_problem* p, void* hip_stream) {
   SFM_TRY(check_problem(p));
   SFM_TRY(ba_flush(p));
   SFM_HIP(hipStreamSynchronize(p->stream));
+  ba_graph_drop(p);
   p->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx().own;
   return SFM_OK;
 }
 
 int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
   SFM_TRY(check_problem(p));
+  ba_graph_drop(p);       // every option changes what an iteration launches
   switch (option) {
+    case SFM_OPT_GRAPH:
+      p->use_graph = value != 0;
+      return SFM_OK;
     case SFM_OPT_SCHUR:
       SFM_TRY(ba_flush(p));
       if (value < SFM_SCHUR_AUTO || value > SFM_SCHUR_ROWS) { set_error("bad schur mode %d", value); return SFM_E_SHAPE; }
@@ -338,6 +344,7 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
     case SFM_INFO_N_PTS: *value = p->dev.N; return SFM_OK;
     case SFM_INFO_N_OBS: *value = p->dev.M; return SFM_OK;
     case SFM_INFO_MAX_TRACK: *value = p->max_track; return SFM_OK;
+    case SFM_INFO_GRAPH_REPLAYS: *value = p->graph_replays; return SFM_OK;
     default: set_error("sfm_ba_info: unknown item %d", what); return SFM_E_SHAPE;
   }
 }
@@ -503,6 +510,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   q->dev.debug = p->debug;
   q->deterministic = p->deterministic && q->schur_mfma_ok && sizeof(double) * (size_t)q->dev.V * 35 <= 64 * 1024;
   const bool had_external_red = p->dev.red != p->own_red;
+  ba_graph_drop(p);
   std::swap(p->dev, q->dev);
   std::swap(p->own_red, q->own_red);
   std::swap(p->schur_ws, q->schur_ws);
@@ -537,6 +545,7 @@ int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_do
   SFM_TRY(check_problem(p));
   SFM_TRY(ba_flush(p));           // the deferred kernel clears the buffer that is bound now
   const int64_t need = (int64_t)red_size(p->dev.nbk);
+  ba_graph_drop(p);
   p->red_clean = false;
   if (device_ptr == nullptr) { p->dev.red = p->own_red; return SFM_OK; }
   if (n_doubles < need) { set_error("reduced buffer too small: %lld < %lld doubles", (long long)n_doubles, (long long)need); return SFM_E_SHAPE; }

@@ -404,6 +404,33 @@ def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm,
     assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
 
 
+@pytest.mark.parametrize("shape", [(6, 800, 1.0), (30, 3000, 0.5), (60, 4000, 0.15)])
+def test_ba_graph_replay_equals_eager_launches(hip, sfm, shape):
+    """SFM_OPT_GRAPH: the iteration body captured as a hipGraph and replayed == the same kernels launched eagerly
+    (bitwise in deterministic mode, 1e-12 otherwise); options, state changes and appends in between are honoured."""
+    sc = sfm.scenes.make_scene(*shape, seed=91)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    for det in (1, 0):
+        out, stats, replays = [], [], []
+        for graph in (0, 1):
+            with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+                prob.set_option(hip.OPT_DETERMINISTIC, det)
+                prob.set_option(hip.OPT_GRAPH, graph)
+                prob.set_state(sc.cams_init, sc.pts_init)
+                prob.iterate(5.0, 6)
+                prob.iterate(5.0, 2)                       # a second call: starts eagerly, then replays
+                prob.iterate(4.0, 3)                       # another lambda: new graphs
+                stats.append(prob.get_stats())
+                out.append(prob.get_state())
+                replays.append(prob.info(hip.INFO_GRAPH_REPLAYS))
+        assert replays[0] == 0 and replays[1] >= 4
+        if det:
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+            assert np.array_equal(stats[0], stats[1])
+        else:
+            assert rel(out[0][0], out[1][0]) < 1e-12 and rel(out[0][1], out[1][1]) < 1e-12
+
+
 def test_ba_split_phases_equal_iterate(hip, sfm):
     """linearize_reduce + solve_update (the multi-GPU split) == iterate on one rank."""
     sc = sfm.scenes.make_scene(7, 500, 0.5, seed=4)
