@@ -138,15 +138,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # SFM_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo (through host memory) where RCCL sits -- the N > 1 control
+    # flow of this file on a one-GPU box; the line it prints is marked and is not a measurement
+    rehearsal = os.environ.get("SFM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = torch.device("cpu") if rehearsal else device      # where the small bookkeeping collectives live
     # Under torch.distributed.run (RANK set) the RCCL path is taken even with one rank, so the same code
     # that runs on 8 GPUs can be exercised on a 1-GPU box; a plain `python bench.py` skips the process group.
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
 
     # ---- workload: C3 weak-scaled (points per rank fixed), C4 strong-scaled (scene fixed) --------------
     cfg = dict(sfm.scenes.CONFIGS[args.config])
@@ -162,6 +168,11 @@ def main():
     schur_mode = {"auto": native.SCHUR_AUTO, "pairs": native.SCHUR_PAIRS, "mfma": native.SCHUR_MFMA, "rows": native.SCHUR_ROWS}[args.schur]
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
     all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_dist else None
+    if use_dist and rehearsal:
+        def all_reduce(t):
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
     ba = sfm.sharding.ShardedBa(engine, all_reduce, world)
 
     def sync():
@@ -206,7 +217,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dom_ms, dom_n = engine.prob.kernel_time(dom_id)
@@ -263,7 +274,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
         "config": {"workload": ("%s: %d cams x %d pts in total @ %.0f%% visibility, strong-scaled: %d..%d pts per rank, lambda=5, Schur BA" % (
                                     args.config, scene.n_cams, scene.n_pts, 100 * cfg["visibility"],
                                     int(np.min(np.diff(bounds))), int(np.max(np.diff(bounds))))) if strong else
@@ -295,7 +306,7 @@ def main():
 
     # ---- N > 1: every rank must hold bit-identical cameras after the redundant solves -----------------
     if use_dist and world > 1:
-        cams_dev = torch.from_numpy(np.ascontiguousarray(cams_end)).to(device)
+        cams_dev = torch.from_numpy(np.ascontiguousarray(cams_end)).to(coll_device)
         ref = cams_dev.clone()
         dist.broadcast(ref, src=0)
         dev = (cams_dev - ref).abs().max().reshape(1)
