@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--pts", type=int, default=None, help="override points per rank (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schur", default="auto", choices=["auto", "pairs", "mfma", "rows"])
+    ap.add_argument("--debug", type=int, default=0, help="SFM_OPT_DEBUG bits for same-box A/B runs of a code path (invalidates the metric)")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +168,8 @@ def main():
     engine = sfm.sharding.HipShardEngine(scene.n_cams, ptr_l, cam_l, uv_l, device)
     schur_mode = {"auto": native.SCHUR_AUTO, "pairs": native.SCHUR_PAIRS, "mfma": native.SCHUR_MFMA, "rows": native.SCHUR_ROWS}[args.schur]
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
+    if args.debug:
+        engine.prob.set_option(native.OPT_DEBUG, args.debug)
     all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_dist else None
     if use_dist and rehearsal:
         def all_reduce(t):
@@ -282,7 +285,7 @@ def main():
                                     args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"])),
             "observations_per_rank": int(cam_l.shape[0]), "points_total": int(scene.n_pts),
             "parallelism": "points sharded x%d, cameras replicated, all-reduce [S|rhs]" % world if world > 1 else "single GPU",
-            "schur": args.schur},
+            "schur": args.schur, **({"debug_bits": args.debug} if args.debug else {})},
         "rmse_px": {"initial": rmse_init, "after_3_iterations": rmse_gpu3, "after_timed_run": rmse_end},
         "kernel_ms": breakdown,
         "roofline": roofline,

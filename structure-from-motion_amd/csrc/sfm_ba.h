@@ -70,6 +70,9 @@ struct BaDev {
   double* red = nullptr;    // [red_size(nbk)] reduced system S (lower-triangular 32x32 blocks) | rhs
   double* delta = nullptr;  // [32 nbk] camera update
   double* ldiag = nullptr;  // [ceil(P/32)][32][32] INVERSE transposed Cholesky factors L_d^-T of the diagonal blocks, k-major
+  double* xinv = nullptr;   // [nbk (nbk + 1) / 2 blocks] X = L^-T, block (e, c >= e) at red_blk_base(c, e): the identity carried
+                            // through the column steps as extra block rows (sfm_ba_solve.hip); dp = X y is one launch
+  int* sync_ctr = nullptr;  // [1] workgroups of ba_inv_apply that have stored their part of dp (self-resetting)
   int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (bit 32: one-wave elimination)
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused

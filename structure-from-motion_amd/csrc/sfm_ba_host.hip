@@ -206,6 +206,8 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   BA_ALLOC(p->own_red, red_size(d.nbk));
   BA_ALLOC(d.delta, (size_t)d.nbk * kNB);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
+  BA_ALLOC(d.xinv, red_rhs_off(d.nbk));
+  BA_ALLOC(d.sync_ctr, 1);
   BA_ALLOC(d.status, 2);
   BA_ALLOC(d.sinfo, 4);
   BA_ALLOC(d.cost, kStatSlots);
@@ -216,6 +218,7 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   if (hipMemsetAsync(d.status, 0, 2 * sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.cost, 0, kStatSlots * sizeof(double), stream) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.iter_count, 0, sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
+  if (hipMemsetAsync(d.sync_ctr, 0, sizeof(int), stream) != hipSuccess) return fail(SFM_E_HIP);
   if (hipMemsetAsync(d.delta, 0, sizeof(double) * d.nbk * kNB, stream) != hipSuccess) return fail(SFM_E_HIP);
   { const int st_plan = ba_schur_plan(p); if (st_plan != SFM_OK) return fail(st_plan); }
   *out = p;
@@ -276,7 +279,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   ba_graph_drop(p);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.xinv, d.sync_ctr, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
                   p->schur_ws, p->schur_blk_ptr, p->cam_ptr, p->cam_ent, p->cam_pairs, p->rows_table, p->rows_first, p->rows_ws};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)

@@ -144,16 +144,22 @@ __device__ __forceinline__ void chol_trsm_cols(double (&c)[8], f64x2 (*xy)[64], 
 // Trailing role of a column step: a 64x64 super-tile (2x2 blocks, one block per wave) of the blocks right of
 // column j gets the previous panel's update A[r][c] -= L[r][j-1] L[c][j-1]^T.  No LDS: every wave loads its four
 // operand tiles and the old block in the MFMA layouts directly.
+// INV = true: the same update for the identity rows, E[e][c] -= X[e][j-1] L[c][j-1]^T (e <= j-1 < c; rectangle, not
+// triangle).  E starts as the identity, so the block (e, c), c > e, is all zero until panel e contributes: the first
+// update (j - 1 == e) writes instead of accumulating and the buffer never needs clearing.
+template <bool INV>
 __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, int sr, int sc) {
   const int nbk = d.nbk;
   double* red = d.red;
   double* rhs = d.red + red_rhs_off(nbk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = j + 1 + 2 * sr + (wave >> 1), c = j + 1 + 2 * sc + (wave & 1);
-  if (!(c <= nbk - 1 && r >= c && r <= nbk)) return;
-  const bool is_rhs = r == nbk;
+  const int r = (INV ? 0 : j + 1) + 2 * sr + (wave >> 1), c = j + 1 + 2 * sc + (wave & 1);
+  if (INV) { if (!(c <= nbk - 1 && r <= j - 1)) return; }
+  else if (!(c <= nbk - 1 && r >= c && r <= nbk)) return;
+  const bool is_rhs = !INV && r == nbk;
+  const bool fresh = INV && r == j - 1;
   const int lr = lane & 15, lk = lane >> 4;
-  double* blk = is_rhs ? nullptr : red + red_blk_base(r, c);
+  double* blk = is_rhs ? nullptr : (INV ? d.xinv + red_blk_base(c, r) : red + red_blk_base(r, c));
   double old[2][2][4];
 #pragma unroll
   for (int sx = 0; sx < 2; ++sx)
@@ -162,14 +168,14 @@ __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, i
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
-        old[sx][sy][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : blk[red_blk_off(i, col)];
+        old[sx][sy][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : (fresh ? 0.0 : blk[red_blk_off(i, col)]);
       }
   double la[2][8], lb[2][8];
   const double* Lc = red + red_blk_base(c, j - 1);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (is_rhs) load_operand_rhs(rhs + (j - 1) * NB, t, lr, lk, la[t]);
-    else load_operand(red + red_blk_base(r, j - 1), t, lr, lk, la[t]);
+    else load_operand(INV ? d.xinv + red_blk_base(j - 1, r) : red + red_blk_base(r, j - 1), t, lr, lk, la[t]);
     load_operand(Lc, t, lr, lk, lb[t]);
   }
   f64x4 acc[2][2];
@@ -197,34 +203,56 @@ __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, i
       }
 }
 
-__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda) {
+// Workgroup roles of column step j (with_inv = the identity rows are carried: dp = X y replaces the back substitution):
+//   [0, ncol)                 column role of block rows j .. nbk (nbk = the rhs row)
+//   [.., + nst)               trailing super-tiles (sr >= sc) of the blocks right of column j
+//   [.., + j)                 column role of the identity rows e = 0 .. j-1:  X[e][j] = (E[e][j] - X[e][j-1] L[j][j-1]^T) L_d^-T
+//   [.., + ceil(j/2) * ncs)   trailing super-tiles of the identity rows
+__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda, int with_inv) {
   constexpr int kSq = NB * (NB + 1);
   __shared__ __attribute__((aligned(16))) double arena[2 * kSq + (NB / 2) * 64 * 2 + 2];
   const int P = d.P, nbk = d.nbk;
-  // workgroups 0 .. nbk-j are the column role (block rows j .. nbk, the last one being the rhs row); the rest are
-  // trailing super-tiles (sr >= sc)
   const int ncol = nbk - j + 1;
-  if ((int)blockIdx.x >= ncol) {
-    int t = blockIdx.x - ncol, sr = 0;
-    while (t > sr) { t -= sr + 1; ++sr; }
-    chol_trailing_supertile(d, j, sr, t);
-    return;
+  const int srn = j > 0 ? (nbk - j + 1) / 2 : 0, nst = srn * (srn + 1) / 2;
+  int role = blockIdx.x;
+  bool inv_row = false;
+  if (role >= ncol) {
+    role -= ncol;
+    if (role < nst) {
+      int t = role, sr = 0;
+      while (t > sr) { t -= sr + 1; ++sr; }
+      chol_trailing_supertile<false>(d, j, sr, t);
+      return;
+    }
+    role -= nst;
+    if (role >= j) {                       // identity rows, trailing
+      role -= j;
+      const int ncs = (nbk - 1 - j + 1) / 2;       // column pairs over c = j+1 .. nbk-1
+      if (ncs > 0) chol_trailing_supertile<true>(d, j, role / ncs, role % ncs);
+      return;
+    }
+    inv_row = true;                        // identity rows, column role: role = e
   }
+  // column roles are the launch's critical path (the dependent pivot chain): when a trailing workgroup shares the
+  // CU, its MFMA waves wait
+  __builtin_amdgcn_s_setprio(2);
   double(*Tm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena);
   double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(arena + kSq);
   f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(arena + 2 * kSq);     // [pair-step][lane] = (x, y)
   int* flag = reinterpret_cast<int*>(arena + 2 * kSq + (NB / 2) * 64 * 2);      // pair-steps published (multi-wave elimination)
   static_assert((2 * kSq) % 2 == 0, "xy must be 16-byte aligned");
-  const int r = j + blockIdx.x;
+  const int r = inv_row ? nbk + 1 + role : j + role;      // nbk + 1 + e marks an identity row (never equal to j or nbk)
+  const int e_row = role;
   const bool is_rhs = r == nbk;
+  const bool fresh = inv_row && e_row == j - 1;           // E[e][j] is still all zero: nothing to load
   // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
   unsigned long long* stamp = (d.stamps && blockIdx.x == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
   double* red = d.red;
   double* rhs = d.red + red_rhs_off(nbk);
-  double* Tblk = red + red_blk_base(is_rhs ? nbk - 1 : r, j);     // never dereferenced for the rhs row
+  double* Tblk = inv_row ? d.xinv + red_blk_base(j, e_row) : red + red_blk_base(is_rhs ? nbk - 1 : r, j);     // never dereferenced for the rhs row
   const double* Dblk = red + red_blk_base(j, j);
-  const int r0 = r * NB, c0 = j * NB, j0 = j * NB;
+  const int r0 = inv_row ? 0 : r * NB, c0 = j * NB, j0 = j * NB;      // identity rows: every row is a real one
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const bool need_d = r != j;
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = 16 * sx + lk + 4 * g;
-    aT[g] = is_rhs ? (i == 0 ? rhs[c0 + ocol] : 0.0) : Tblk[red_blk_off(i, ocol)];
+    aT[g] = is_rhs ? (i == 0 ? rhs[c0 + ocol] : 0.0) : (fresh ? 0.0 : Tblk[red_blk_off(i, ocol)]);
     if (need_d) aD[g] = Dblk[red_blk_off(i, ocol)];
   }
   if (j > 0) {
@@ -251,7 +279,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
     const double* Lj = red + red_blk_base(j, j - 1);
     load_operand(Lj, sy, lr, lk, lb);
     if (is_rhs) load_operand_rhs(rhs + (j - 1) * NB, sx, lr, lk, la);
-    else load_operand(red + red_blk_base(r, j - 1), sx, lr, lk, la);
+    else load_operand(inv_row ? d.xinv + red_blk_base(j - 1, e_row) : red + red_blk_base(r, j - 1), sx, lr, lk, la);
     if (need_d) load_operand(Lj, sx, lr, lk, lja);
     if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
     // previous-panel update on the matrix pipe: T -= L[r][j-1] L[j][j-1]^T, D -= L[j][j-1] L[j][j-1]^T.
@@ -268,7 +296,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int i = 16 * sx + lk + 4 * g;
-    const bool row_ok = is_rhs ? (i == 0) : (r0 + i < P);
+    const bool row_ok = is_rhs ? (i == 0) : (inv_row || r0 + i < P);
     double t = (row_ok && col_ok) ? aT[g] : 0.0;
     if (r == j) {                      // this block IS the diagonal block: D = T + lambda I (identity on padding)
       if (i == ocol) t = col_ok ? t + lambda : 1.0;
@@ -300,7 +328,12 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
         // row `row` of X = L_d^-T (upper triangular), stored k-major: ldiag[j][k][i] = X[i][k]
         double* out = d.ldiag + (size_t)j * NB * NB + row;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = 8 * wave + u; out[k * NB] = (k >= row) ? c[u] : 0.0; }
+        for (int u = 0; u < 8; ++u) { const int k = 8 * wave + u; c[u] = (k >= row) ? c[u] : 0.0; out[k * NB] = c[u]; }
+        if (with_inv) {                  // ... and as the identity row's first block X[j][j], in the operand layout
+          double* out2 = d.xinv + red_blk_base(j, j) + wave * 256 + row * 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f64x2*>(out2 + q * 64) = f64x2{c[q], c[q + 4]};
+        }
       } else if (is_rhs) {
         if (row == 0) {
 #pragma unroll
@@ -329,7 +362,15 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
       // its row with coalesced loads: ldiag[j][k][i] = X[i][k]
       double* out = d.ldiag + (size_t)j * NB * NB + row;
 #pragma unroll
-      for (int k = 0; k < NB; ++k) out[k * NB] = (k >= row) ? a[k] : 0.0;
+      for (int k = 0; k < NB; ++k) { a[k] = (k >= row) ? a[k] : 0.0; out[k * NB] = a[k]; }
+      if (with_inv) {
+        double* out2 = d.xinv + red_blk_base(j, j) + row * 2;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f64x2*>(out2 + m * 256 + q * 64) = f64x2{a[8 * m + q], a[8 * m + q + 4]};
+      }
     }
   } else if (lane >= NB) {
     if (is_rhs) {
@@ -492,6 +533,67 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ red, int P, doub
   if (idx >= P * P) return;
   const int i = idx / P, j = idx % P;
   out[idx] = red[red_index(max(i, j), min(i, j))] + (i == j ? lambda : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dp = X y with X = L^-T from the identity rows of the column steps and y = L^-1 rhs from the rhs row: the whole
+// back substitution as ONE launch of independent block rows (it was 11 dependent block steps of ~2 us at V = 50,
+// 44 in four groups at V = 200).  Workgroup e: dp_e = sum_{c >= e} X[e][c] y_c; thread (row i, slice) takes every
+// 32nd block column, a block row as sixteen 16-byte loads per thread (32 x 16 contiguous bytes across the lanes).
+// The workgroup that finishes last (release / acquire through a device counter) does the camera update of
+// ba:383-392 and prepares the next iteration's cameras: 8.0 us in all at V = 50 against 4.8 + 5.0 us with the camera
+// update as its own launch (12.4 against 7.4 + 4.2 at V = 200).
+constexpr int IA_THREADS = 1024;      // 32 rows x 32 slices of block columns
+__global__ __launch_bounds__(IA_THREADS) void ba_inv_apply_kernel(BaDev d, int cur) {
+  __shared__ double part[IA_THREADS / 32][NB + 1];
+  __shared__ int is_last;
+  const int nbk = d.nbk, e = blockIdx.x;
+  const int tid = threadIdx.x, i = tid & 31, slice = tid >> 5;
+  const double* __restrict__ y = d.red + red_rhs_off(nbk);
+  double s = 0;
+  for (int c = e + slice; c < nbk; c += IA_THREADS / 32) {
+    const double* blk = d.xinv + red_blk_base(c, e) + 2 * i;
+    const double* yc = y + c * NB;
+    f64x2 w[16];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[4 * m + q] = *reinterpret_cast<const f64x2*>(blk + m * 256 + q * 64);      // columns 8m+q, 8m+q+4
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s = __builtin_fma(w[4 * m + q].y, yc[8 * m + q + 4], __builtin_fma(w[4 * m + q].x, yc[8 * m + q], s));
+  }
+  part[slice][i] = s;
+  __syncthreads();
+  if (tid < NB) {
+    double t = 0;
+#pragma unroll
+    for (int q = 0; q < IA_THREADS / 32; ++q) t += part[q][tid];
+    d.delta[e * NB + tid] = t;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(d.sync_ctr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = done == nbk - 1;
+    if (is_last) __hip_atomic_store(d.sync_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next solve
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
+  for (int c = tid; c < d.V; c += IA_THREADS) {
+    double cam[7];
+    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * c + k] + d.delta[7 * c + k];          // ba:383
+    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
+    for (int k = 3; k < 7; ++k) cam[k] /= nq;
+    for (int k = 0; k < 7; ++k) d.cams[7 * c + k] = cam[k];
+    CamPrep out;
+    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
+    d.prep[cur ^ 1][c] = out;
+    report_status(d.status, st, c);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,12 +772,21 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
     SFM_HIP(hipGetLastError());
     return SFM_OK;
   }
+  // the identity rows ride along (SFM_OPT_DEBUG bit 512: leave them out and back-substitute block row by block row)
+  const bool with_inv = !(d.debug & 512);
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
     // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
     // j+1 .. nbk-1, lower part only
     const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
-    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2, 256, 0, s>>>(d, j, lambda);
+    // identity rows e < j: j column workgroups, ceil(j/2) x ceil((nbk-1-j)/2) trailing super-tiles
+    const int ninv = with_inv ? j + ((j + 1) / 2) * ((nbk - 1 - j + 1) / 2) : 0;
+    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2 + ninv, 256, 0, s>>>(d, j, lambda, with_inv ? 1 : 0);
+  }
+  if (with_inv) {
+    ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
+    SFM_HIP(hipGetLastError());
+    return SFM_OK;
   }
   // back substitution in groups of at most 28 block rows, from the bottom; between two groups one multi-workgroup
   // launch folds the finished group into everything above it

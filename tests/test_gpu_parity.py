@@ -384,6 +384,25 @@ def test_ba_fused_and_separate_launches_agree(hip, sfm):
     assert rel(out[0][0], out[1][0]) < 1e-13 and rel(out[0][1], out[1][1]) < 1e-13
 
 
+@pytest.mark.parametrize("n_cams,n_pts,vis", [(9, 900, 0.8), (14, 1500, 0.5), (37, 2500, 0.4), (131, 4000, 0.1)])
+def test_ba_inverse_rows_against_block_back_substitution(hip, oracle, sfm, n_cams, n_pts, vis):
+    """dp = X y with X = L^-T carried through the column steps as identity rows (default) against the block-row back
+    substitution (SFM_OPT_DEBUG bit 512), and both against the oracle: 2, 4, 9 and 29 block columns."""
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=300 + n_cams)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    out = []
+    for dbg in (0, 512):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            out.append(prob.get_state())
+    for cams, pts in out:
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+    assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
+
+
 @pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
 def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
     """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;
