@@ -69,6 +69,8 @@ extern "C" {
                                  * reduced solve) as a hipGraph -- one per camera-slot parity -- and replays it for every iteration
                                  * after the first; same kernels, same arguments, same results.  Off by default: on this stack the
                                  * kernels of an iteration already run back to back from eager launches. */
+#define SFM_OPT_TIMING_STRIDE 6 /* bracket a timed kernel class only every value-th time it runs (default 1): an event pair costs two
+                                 * ~6 us stream bubbles on this stack, so a measurement that must not disturb what it measures samples */
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */

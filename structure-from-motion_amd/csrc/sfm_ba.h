@@ -114,6 +114,8 @@ __device__ __forceinline__ void cam_reduce_slice(const BaDev& d, int nrows, int 
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int used = 0;
+  int calls = 0;         // brackets seen since the last reset (SFM_OPT_TIMING_STRIDE samples every stride-th)
+  bool open = false;     // the current bracket is a sampled one
 };
 
 constexpr unsigned kBaMagic = 0x5F3BA001u;
@@ -139,6 +141,7 @@ struct sfm_ba_problem {
   int debug = 0;             // SFM_OPT_DEBUG: profiling ablations (results are wrong when set)
   int deterministic = 0;     // SFM_OPT_DETERMINISTIC: fixed summation order everywhere (bitwise repeatable results)
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
+  int timing_stride = 1;     // ... every stride-th time they run (an event pair costs ~11 us of stream bubbles on this stack)
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles

@@ -419,15 +419,18 @@ void ba_tick(sfm_ba_problem* p, int kid, bool begin, hipStream_t s) {
   if (!(p->timing & (1 << kid))) return;
   KernelTimer& t = p->timers[kid];
   if (begin) {
+    t.open = (t.calls++ % p->timing_stride) == 0;
+    if (!t.open) return;
     if (t.used == (int)t.ev.size()) {
       hipEvent_t a, b;
       (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       t.ev.push_back({a, b});
     }
     (void)hipEventRecord(t.ev[t.used].first, s);
-  } else {
+  } else if (t.open) {
     (void)hipEventRecord(t.ev[t.used].second, s);
     t.used++;
+    t.open = false;
   }
 }
 

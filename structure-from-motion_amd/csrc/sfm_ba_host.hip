@@ -322,6 +322,10 @@ int sfm_ba_set_option(sfm_ba_problem* p, int option, int value) {
     case SFM_OPT_TIMING:
       p->timing = value;   // bit k set = time kernel class k
       return SFM_OK;
+    case SFM_OPT_TIMING_STRIDE:
+      if (value < 1) { set_error("timing stride %d < 1", value); return SFM_E_SHAPE; }
+      p->timing_stride = value;
+      return SFM_OK;
     case SFM_OPT_DETERMINISTIC:
       SFM_TRY(ba_flush(p));
       if (value != 0) {
@@ -583,7 +587,7 @@ int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n) {
 int sfm_ba_reset_timing(sfm_ba_problem* p) {
   SFM_TRY(check_problem(p));
   SFM_HIP(hipStreamSynchronize(p->stream));
-  for (auto& t : p->timers) t.used = 0;
+  for (auto& t : p->timers) { t.used = 0; t.calls = 0; t.open = false; }
   return SFM_OK;
 }
 

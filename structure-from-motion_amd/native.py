@@ -18,7 +18,7 @@ OK = 0
 E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK = -1, -2, -3, -4, -5, -6, -7, -8
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
 SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA, SCHUR_ROWS = 0, 1, 2, 3
-OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC, OPT_GRAPH = 1, 2, 3, 4, 5
+OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC, OPT_GRAPH, OPT_TIMING_STRIDE = 1, 2, 3, 4, 5, 6
 K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
 INFO_SCHUR_KERNEL, INFO_UPLOAD_BYTES, INFO_N_CAMS, INFO_N_PTS, INFO_N_OBS, INFO_MAX_TRACK, INFO_GRAPH_REPLAYS = 1, 2, 3, 4, 5, 6, 7
