@@ -4,7 +4,7 @@
 src=gpurun_out/${1:?tag}
 dst=profiles/${2:-r2}
 mkdir -p "$dst"
-for f in kernel_stats_c3.csv kernel_stats_c4share.csv pmc_sq_summary.csv traffic.json microbench_solve.txt microbench_elim.txt steps.log; do
+for f in trace_iteration_c3.txt trace_iteration_c4share.txt kernel_stats_c3.csv kernel_stats_c4share.csv pmc_sq_summary.csv traffic.json microbench_solve.txt microbench_elim.txt steps.log; do
   [ -f "$src/$f" ] && cp "$src/$f" "$dst/$f"
 done
 for f in bench bench_c4_share bench_c4_full bench_tri_pnp probe_solve time_schur; do

@@ -20,7 +20,7 @@ step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600
 tail -3 "$out/pytest_gpu.log"
 step 120 "$out/smoke.log" python __graft_entry__.py smoke
 tail -1 "$out/smoke.log"
-step 300 "$out/bench.log" python bench.py --steps 20 --warmup 3
+step 300 "$out/bench.log" python bench.py
 tail -c 400 "$out/bench.log"
 step 240 "$out/bench_c4_share.log" python bench.py --config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline
 step 240 "$out/bench_c4_full.log" python bench.py --config C4 --steps 5 --warmup 1 --no-cpu-baseline
@@ -32,13 +32,14 @@ step 60 "$out/stamps_small.log" python tools/stamps_small.py
 step 60 "$out/microbench_solve.txt" tools/bin/microbench_solve
 step 60 "$out/microbench_elim.txt" tools/bin/microbench_elim
 for cfg in c3 c4share; do
-  if [ $cfg = c3 ]; then args="--steps 20 --warmup 3 --no-cpu-baseline"; else args="--config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline"; fi
+  if [ $cfg = c3 ]; then args="--no-cpu-baseline"; pargs="--steps 5 --warmup 3 --no-cpu-baseline"; else args="--config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline"; pargs=$args; fi
   step 300 "$out/rocprof_$cfg.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$cfg" -- python3 bench.py $args
   f=$(find "$out/prof_$cfg" -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$out/kernel_stats_$cfg.csv" && head -12 "$f"
+  python3 tools/trace_iteration.py "$out/prof_$cfg" > "$out/trace_iteration_$cfg.txt" 2>&1
   # HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots), no other trace domains
-  step 300 "$out/pmc_fetch_$cfg.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$cfg" -- python3 bench.py ${args/--steps 20/--steps 5}
-  step 300 "$out/pmc_write_$cfg.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$cfg" -- python3 bench.py ${args/--steps 20/--steps 5}
+  step 300 "$out/pmc_fetch_$cfg.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch_$cfg" -- python3 bench.py $pargs
+  step 300 "$out/pmc_write_$cfg.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write_$cfg" -- python3 bench.py $pargs
   if [ $cfg = c3 ]; then blog="$out/bench.log"; else blog="$out/bench_c4_share.log"; fi
   key=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['roofline']['traffic_key'])" "$blog")
   python3 tools/parse_pmc.py "$out/pmc_fetch_$cfg" "$out/pmc_write_$cfg" "$out/traffic.json" "$key"
