@@ -1,0 +1,65 @@
+"""Property-based GPU parity (hypothesis): random small scenes -- camera count, point count, visibility, damping,
+iteration count, quirk flags, Schur kernel, solve path -- through the C-ABI against the CPU oracle, plus the
+size-independent properties the bundle-adjustment step has (cost history, idempotence of zero iterations, invariance
+under the order in which the same observations are appended).  Sizes are kept to what the oracle does in
+milliseconds; the example database is disabled so that a run never depends on local state."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+SETTINGS = dict(max_examples=40, deadline=None, database=None, derandomize=True,
+                suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+scene_args = st.tuples(st.integers(2, 21), st.integers(8, 400), st.sampled_from([0.25, 0.5, 0.8, 1.0]), st.integers(0, 10_000))
+
+
+@settings(**SETTINGS)
+@given(args=scene_args, lam=st.sampled_from([0.5, 5.0, 50.0]), iters=st.integers(1, 4),
+       mode=st.sampled_from(["auto", "pairs", "mfma", "rows"]), debug=st.sampled_from([0, 16, 32, 64, 256, 512]))
+def test_ba_random_scene_matches_oracle(hip, oracle, sfm, args, lam, iters, mode, debug):
+    n_cams, n_pts, vis, seed = args
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=seed)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, lam, iters)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, {"auto": hip.SCHUR_AUTO, "pairs": hip.SCHUR_PAIRS, "mfma": hip.SCHUR_MFMA, "rows": hip.SCHUR_ROWS}[mode])
+        prob.set_option(hip.OPT_DEBUG, debug)          # result-preserving code-path switches only (include/sfm_hip.h)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(lam, iters)
+        cams, pts = prob.get_state()
+        cost = prob.get_stats()
+    assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+    assert cost.shape == (iters,) and np.all(np.isfinite(cost)) and np.all(cost > 0)
+    # quaternions stay unit (ba:388-392)
+    assert np.max(np.abs(np.linalg.norm(cams[:, 3:7], axis=1) - 1.0)) < 1e-14
+
+
+@settings(**{**SETTINGS, "max_examples": 15})
+@given(args=scene_args, split=st.floats(0.2, 0.8))
+def test_ba_append_order_does_not_change_the_result(hip, sfm, args, split):
+    """The same scene built in one piece and grown by an append (new points with their observations) iterates to the
+    same state: the merged CSR equals the one-piece CSR."""
+    n_cams, n_pts, vis, seed = args
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=seed)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    n0 = max(1, min(n_pts - 1, int(split * n_pts)))
+    m0 = int(sc.pt_ptr[n0])
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as whole:
+        whole.set_state(sc.cams_init, sc.pts_init)
+        whole.iterate(5.0, 2)
+        want = whole.get_state()
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr[:n0 + 1], sc.cam_idx[:m0], uvn[:, :m0]) as grown:
+        grown.set_state(sc.cams_init, sc.pts_init[:, :n0])
+        grown.append(np.zeros((0, 7)), sc.pts_init[:, n0:], sc.cam_idx[m0:], sc.pt_idx[m0:], uvn[:, m0:])
+        grown.iterate(5.0, 2)
+        got = grown.get_state()
+    assert rel(got[0], want[0]) < 1e-12 and rel(got[1], want[1]) < 1e-12
