@@ -92,10 +92,13 @@ __device__ __forceinline__ void report_status(int* status, int code, int index) 
 }
 
 // Cross-lane moves on the DPP path (no LDS crossbar): quad_perm xor-1 / xor-2, row_half_mirror, row_mirror.
+// bound_ctrl = 1: every source lane of these patterns is valid, so the flag changes no value -- but it tells the
+// compiler that the destination's old contents are dead, which saves a v_mov_b32 0 per half (8 of the 20
+// instructions of a 16-lane sum).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
