@@ -543,6 +543,7 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ red, int P, doub
 // The workgroup that finishes last (release / acquire through a device counter) does the camera update of
 // ba:383-392 and prepares the next iteration's cameras: 8.0 us in all at V = 50 against 4.8 + 5.0 us with the camera
 // update as its own launch (12.4 against 7.4 + 4.2 at V = 200).
+constexpr int kInvRowsMaxNbk = 52;
 constexpr int IA_THREADS = 1024;      // 32 rows x 32 slices of block columns
 __global__ __launch_bounds__(IA_THREADS) void ba_inv_apply_kernel(BaDev d, int cur) {
   __shared__ double part[IA_THREADS / 32][NB + 1];
@@ -772,8 +773,11 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
     SFM_HIP(hipGetLastError());
     return SFM_OK;
   }
-  // the identity rows ride along (SFM_OPT_DEBUG bit 512: leave them out and back-substitute block row by block row)
-  const bool with_inv = !(d.debug & 512);
+  // the identity rows ride along (SFM_OPT_DEBUG bit 512: leave them out and back-substitute block row by block row).
+  // Their trailing updates grow with nbk^3 while the back substitution they replace grows with nbk: measured
+  // (tools/time_solve_paths.py) 153 vs 198 us at nbk = 20, 293 vs 340 at 35, 422 vs 448 at 44, 643 vs 640 at 57,
+  // 932 vs 910 at 75 -- used up to 52 block columns (V <= 237)
+  const bool with_inv = !(d.debug & 512) && nbk <= kInvRowsMaxNbk;
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
     // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
