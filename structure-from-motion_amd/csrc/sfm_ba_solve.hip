@@ -2,18 +2,25 @@
 //   dp = inv(A - B D^-1 B^T) (ep - B D^-1 ex)        (ba_processor.py:382)
 //   cams += dp ; q <- q / |q|                        (ba_processor.py:383-392)
 // as a blocked right-looking Cholesky of S + lambda I on the packed 32x32 blocks of BaDev::red (layout:
-// sfm_ba.h), the right-hand side carried as an extra block row, and a blocked back substitution.
+// sfm_ba.h), the right-hand side carried as an extra block row, and dp = L^-T y either as one product with the
+// explicitly carried L^-T or as a blocked back substitution.
 //
 //   ba_chol_step   one launch per block column j.  Column-role workgroup (r, j), r = j .. nbk (nbk = the rhs
 //                  row): T = A[r][j] - L[r][j-1] L[j][j-1]^T and D = A[j][j] - L[j][j-1] L[j][j-1]^T on the matrix
 //                  pipe, the operand tiles loaded straight from the k-interleaved blocks into registers (four
 //                  16-byte loads per 16x32 tile, no LDS staging, no barrier before the MFMAs); [D; T] then goes
-//                  through LDS to ONE wave that factors D and solves X L_d^T = T in the same instruction stream
-//                  (lanes 0-31 = rows of D, lanes 32-63 = rows of T), two columns per step (2x2 pivots: the two
-//                  reciprocal square roots of a step are independent).  Trailing-role workgroups give the 64x64
+//                  through LDS to a four-wave, column-split elimination (chol_trsm_cols; one wave with SFM_OPT_DEBUG
+//                  bit 32) that factors D and solves X L_d^T = T in the same instruction stream (lanes 0-31 = rows
+//                  of D, lanes 32-63 = rows of T), two columns per step (2x2 pivots: the two reciprocal square
+//                  roots of a step are independent).  Trailing-role workgroups give the 64x64
 //                  super-tiles right of column j the update of panel j-1, again register-to-register.
-//   ba_back_solve  L^T dp = y with the inverse diagonal factors the factorisation left behind, camera update,
-//                  preparation of the next iteration's cameras.
+//                  Identity rows (nbk <= 52): the P x P identity rides through the same column steps as extra block
+//                  rows, so the launches that factor S also leave X = L^-T behind.
+//   ba_inv_apply   dp = X y (y = L^-1 rhs sits in the rhs row): one launch of independent block rows; the last workgroup
+//                  updates the cameras and prepares the next iteration's.
+//   ba_back_solve  (nbk > 52, or SFM_OPT_DEBUG bit 512) L^T dp = y block row by block row with the inverse diagonal
+//                  factors the factorisation left behind, ba_back_update between groups of block rows.
+//   ba_small_solve P <= 56: the whole solve in one single-workgroup launch (whole-matrix multi-wave elimination).
 #include <algorithm>
 
 #include "sfm_ba.h"
