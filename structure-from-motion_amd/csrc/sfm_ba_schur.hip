@@ -367,7 +367,10 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
     if (v.kA <= 0 || v.kB <= 0) { v.kA = 0; return; }
     v.ca_lane = 7 * TP * (cam_idx[v.a0 + (lane < v.kA ? lane : 0)] - ti * CB);
     const bool on = lane < 7 * v.kB;
-    const int b = on ? lane / 7 : 0, j = lane - 7 * b;
+    // idle lanes read element 0 of the block's first observation: an offset built from their lane number ran up to
+    // 1.5 KB (3 KB in the second lane round) past the END of Z for the last observations of the list -- harmless
+    // inside a pooled block, a memory fault when a tiny scene's Z is the last thing on its page
+    const int b = on ? lane / 7 : 0, j = on ? lane - 7 * b : 0;
     const double* zb = Z + (size_t)(v.b0 + b) * 21 + 3 * j;
     v.zb0 = zb[0]; v.zb1 = zb[1]; v.zb2 = zb[2];
     v.col = on ? 7 * (cam_idx[v.b0 + b] - tj * CB) + j : -1;
@@ -405,7 +408,7 @@ __device__ __forceinline__ void pairs_tile_body(const BaDev& d, const int* __res
       if (7 * cur.kB > 64) {                    // second lane round (more than 9 observations in block B)
         const int l = 64 + lane;
         const bool on = l < 7 * cur.kB;
-        const int b = on ? l / 7 : 0, j = l - 7 * b;
+        const int b = on ? l / 7 : 0, j = on ? l - 7 * b : 0;
         const double* zb = Z + (size_t)(cur.b0 + b) * 21 + 3 * j;
         products(cur, b, zb[0], zb[1], zb[2], on ? 7 * (cam_idx[cur.b0 + b] - tj * CB) + j : -1);
       }

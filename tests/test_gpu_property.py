@@ -14,6 +14,16 @@ SETTINGS = dict(max_examples=120, deadline=None, database=None, derandomize=True
                 suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
+def trace(*what):
+    """SFM_TRACE_EXAMPLES=<file>: append every generated example before it runs (a GPU fault leaves no Python
+    traceback of the example that caused it)."""
+    import os
+    f = os.environ.get("SFM_TRACE_EXAMPLES")
+    if f:
+        with open(f, "a") as fh:
+            fh.write(repr(what) + "\n")
+
+
 def rel(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
@@ -27,6 +37,7 @@ scene_args = st.tuples(st.integers(2, 21), st.integers(8, 400), st.sampled_from(
        mode=st.sampled_from(["auto", "pairs", "mfma", "rows"]), debug=st.sampled_from([0, 16, 32, 64, 256, 512]))
 def test_ba_random_scene_matches_oracle(hip, oracle, sfm, args, lam, iters, mode, debug):
     n_cams, n_pts, vis, seed = args
+    trace("ba", args, lam, iters, mode, debug)
     sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=seed)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, lam, iters)

@@ -16,7 +16,8 @@ step() {   # step <seconds> <logfile> <cmd...>
   if [ $rc -ge 124 ]; then echo "step killed; stopping" | tee -a "$out/steps.log"; exit $rc; fi
   return 0
 }
-step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600
+export SFM_TRACE_EXAMPLES="$out/examples.log"
+step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600 --capture=sys
 tail -3 "$out/pytest_gpu.log"
 step 120 "$out/smoke.log" python __graft_entry__.py smoke
 tail -1 "$out/smoke.log"
