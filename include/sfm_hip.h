@@ -101,6 +101,10 @@ int sfm_shutdown(void);
  * A resident BA problem keeps the stream it was given (sfm_ba_set_stream), whatever this is set to later. */
 int sfm_set_stream(void* hip_stream);
 int sfm_synchronize(void);
+/* Diagnostic: 1 when the process runs with SFM_POOL_REDZONE=1 -- every device buffer of the library then sits between
+ * two 4 KB zones of 0xA5 that are checked (after a device-wide synchronise) whenever the buffer goes back to the pool;
+ * a kernel that wrote outside its buffer aborts the process with a message.  For test runs only. */
+int sfm_pool_redzone_active(void);
 const char* sfm_last_error(void);
 
 /* ---- unit-level helpers (parity hooks; batched) ------------------------------------------------ */

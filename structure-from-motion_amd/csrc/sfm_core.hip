@@ -3,6 +3,8 @@
 //
 //   tri_nonlinear_kernel  <-> TriangulationProcessor.nonlinear_triangulate (triangulation_processor.py:160-234)
 //   pnp_nonlinear_kernel  <-> CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459)
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -55,10 +57,11 @@ int ensure_init() {
 // device-memory pool (see sfm_common.h)
 // ---------------------------------------------------------------------------------------------
 namespace {
+struct Block { void* base; size_t size; size_t bytes; };    // hipMalloc'ed block, rounded size, bytes the caller asked for
 struct Pool {
   std::mutex mu;
-  std::unordered_map<void*, size_t> live;                 // block -> rounded size
-  std::unordered_map<size_t, std::vector<void*>> free_by_size;
+  std::unordered_map<void*, Block> live;                  // pointer handed out -> its block
+  std::unordered_map<size_t, std::vector<void*>> free_by_size;   // rounded size -> cached block bases
   size_t cached_bytes = 0;
 };
 Pool& pool() {
@@ -71,51 +74,90 @@ size_t round_up_pow2(size_t n) {
   return r;
 }
 constexpr size_t kPoolCap = (size_t)2 << 30;
+// SFM_POOL_REDZONE=1 (tests): every buffer sits between two 4 KB zones filled with 0xA5; pool_free waits for the
+// device, reads them back and aborts with a message if a kernel wrote outside its buffer.  Out-of-bounds READS stay
+// invisible to it (their values are discarded by construction or they would show up as parity failures).
+constexpr size_t kRedZone = 4096;
+bool redzone_on() {
+  static const bool on = [] { const char* e = std::getenv("SFM_POOL_REDZONE"); return e && e[0] == '1'; }();
+  return on;
+}
+void redzone_fill(const Block& b, void* user) {
+  char* base = static_cast<char*>(b.base);
+  char* end = static_cast<char*>(user) + b.bytes;
+  (void)hipMemset(base, 0xA5, kRedZone);
+  (void)hipMemset(end, 0xA5, (size_t)(base + b.size - end));
+}
+void redzone_check(const Block& b, void* user) {
+  (void)hipDeviceSynchronize();
+  char* base = static_cast<char*>(b.base);
+  char* end = static_cast<char*>(user) + b.bytes;
+  const size_t tail = (size_t)(base + b.size - end);
+  std::vector<unsigned char> h(std::max(kRedZone, tail));
+  auto scan = [&](const char* what, const char* dev, size_t n) {
+    (void)hipMemcpy(h.data(), dev, n, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < n; ++i)
+      if (h[i] != 0xA5) {
+        std::fprintf(stderr, "sfm pool red zone: a kernel wrote %s a %zu-byte buffer (offset %zu of the zone)\n", what, b.bytes, i);
+        std::abort();
+      }
+  };
+  scan("BEFORE", base, kRedZone);
+  scan("PAST THE END OF", end, tail);
+}
 }  // namespace
 
 hipError_t pool_alloc(void** ptr, size_t bytes) {
-  const size_t sz = round_up_pow2(bytes);
+  const bool rz = redzone_on();
+  const size_t sz = round_up_pow2(bytes + (rz ? 2 * kRedZone : 0));
   Pool& P = pool();
+  void* base = nullptr;
   {
     std::lock_guard<std::mutex> g(P.mu);
     auto it = P.free_by_size.find(sz);
     if (it != P.free_by_size.end() && !it->second.empty()) {
-      *ptr = it->second.back();
+      base = it->second.back();
       it->second.pop_back();
       P.cached_bytes -= sz;
-      P.live[*ptr] = sz;
-      return hipSuccess;
     }
   }
-  hipError_t e = hipMalloc(ptr, sz);
-  if (e != hipSuccess) {               // out of memory: drop the cache and retry once
-    pool_release_all();
-    e = hipMalloc(ptr, sz);
+  if (base == nullptr) {
+    hipError_t e = hipMalloc(&base, sz);
+    if (e != hipSuccess) {               // out of memory: drop the cache and retry once
+      pool_release_all();
+      e = hipMalloc(&base, sz);
+    }
+    if (e != hipSuccess) return e;
   }
-  if (e == hipSuccess) {
-    std::lock_guard<std::mutex> g(P.mu);
-    P.live[*ptr] = sz;
-  }
-  return e;
+  *ptr = rz ? static_cast<char*>(base) + kRedZone : base;
+  const Block b{base, sz, bytes};
+  if (rz) redzone_fill(b, *ptr);
+  std::lock_guard<std::mutex> g(P.mu);
+  P.live[*ptr] = b;
+  return hipSuccess;
 }
 
 void pool_free(void* ptr) {
   if (ptr == nullptr) return;
   Pool& P = pool();
-  size_t sz = 0;
+  Block b{};
   {
     std::lock_guard<std::mutex> g(P.mu);
     auto it = P.live.find(ptr);
     if (it == P.live.end()) { (void)hipFree(ptr); return; }     // not ours (defensive)
-    sz = it->second;
+    b = it->second;
     P.live.erase(it);
-    if (P.cached_bytes + sz <= kPoolCap) {
-      P.free_by_size[sz].push_back(ptr);
-      P.cached_bytes += sz;
+  }
+  if (redzone_on()) redzone_check(b, ptr);
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.cached_bytes + b.size <= kPoolCap) {
+      P.free_by_size[b.size].push_back(b.base);
+      P.cached_bytes += b.size;
       return;
     }
   }
-  (void)hipFree(ptr);
+  (void)hipFree(b.base);
 }
 
 void pool_release_all() {
@@ -784,6 +826,8 @@ int sfm_synchronize(void) {
   SFM_TRY(stream_sync(ctx().stream));
   return SFM_OK;
 }
+
+int sfm_pool_redzone_active(void) { return redzone_on() ? 1 : 0; }
 
 int sfm_quat_to_rot(int n, const double* q, double* R, int* status) {
   SFM_TRY(ensure_init());

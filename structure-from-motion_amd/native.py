@@ -33,7 +33,7 @@ EXPORTS = (
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
     "sfm_ba_set_stream", "sfm_ba_info", "sfm_ba_set_cameras", "sfm_ba_set_points", "sfm_ba_get_stats", "sfm_ba_flush",
-    "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
+    "sfm_pool_redzone_active", "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
 )
@@ -165,6 +165,11 @@ def set_stream(stream_ptr):
 
 def synchronize():
     check(load().sfm_synchronize())
+
+
+def pool_redzone_active():
+    """True when the process runs with SFM_POOL_REDZONE=1 (device buffers between checked guard zones; tests only)."""
+    return bool(load().sfm_pool_redzone_active())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -233,3 +233,11 @@ def test_packed_reduced_buffer_matches_oracle(hip, sfm, oracle, n_cams, mode):
     assert np.max(np.abs(rhs_gpu - t["rhs"])) < 1e-10 * np.max(np.abs(t["rhs"]))
     # the round trip through pack_reduced reproduces every byte the device wrote: padding and upper parts are zero
     assert np.array_equal(sh.pack_reduced(s_gpu, rhs_gpu), host)
+
+
+def test_pool_red_zone_mode_follows_the_environment(hip):
+    """tools/gpu_round.sh runs the GPU suite a second time with SFM_POOL_REDZONE=1 (every device buffer between two
+    checked 4 KB guard zones: an out-of-bounds WRITE of any kernel aborts with a message); this only checks that the
+    library honours the variable."""
+    import os
+    assert hip.pool_redzone_active() == (os.environ.get("SFM_POOL_REDZONE", "0") == "1")

@@ -14,6 +14,7 @@ for f in time_small stamps_small; do
   [ -f "$src/$f.log" ] && grep -v amdgpu.ids "$src/$f.log" > "$dst/$f.txt"
 done
 tail -3 "$src/pytest_gpu.log" > "$dst/pytest_gpu_tail.txt"
+[ -f "$src/pytest_gpu_redzone.log" ] && tail -1 "$src/pytest_gpu_redzone.log" > "$dst/pytest_gpu_redzone_tail.txt"
 tail -2 "$src/smoke.log" > "$dst/smoke_tail.txt"
 python3 - "$src/traffic.json" profiles/traffic.json <<'PY'
 import json, sys
