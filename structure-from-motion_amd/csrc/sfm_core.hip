@@ -109,7 +109,9 @@ void redzone_check(const Block& b, void* user) {
 
 hipError_t pool_alloc(void** ptr, size_t bytes) {
   const bool rz = redzone_on();
-  const size_t sz = round_up_pow2(bytes + (rz ? 2 * kRedZone : 0));
+  // 4 KB of slack behind every buffer even without the red zones: a read a little past the end (an idle lane's
+  // address) then lands in memory the library owns instead of on an unmapped page
+  const size_t sz = round_up_pow2(bytes + (rz ? 2 * kRedZone : kRedZone));
   Pool& P = pool();
   void* base = nullptr;
   {
