@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD spec; v_mfma_f64_16x16x4 measured 77.8, profiles/microbench_fp64_r01.txt)
 LDS_ADD_PEAK_TADDS = 4.8    # ds_add_f64, conflict-free, all 256 CUs (profiles/microbench_fp64_r01.txt; 2.4 at random addresses)
-TIMING_STRIDE = 4      # the dominant kernel is bracketed by hipEvents on every 4th launch of the timed region
+TIMING_STRIDE = 0      # 0: bracket the dominant kernel with hipEvents on every n-th launch, n = min(10, steps // 5): at least five samples
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md
 LAMBDA = 5.0                # reference default damping_factor (ba_processor.py:24)
 
@@ -214,9 +214,10 @@ def main():
     dom_id = native.KERNEL_NAMES.index(dominant)
 
     # ---- timed region: exactly K steps, only the dominant kernel bracketed by hipEvents ----------
-    # (every 4th launch only: a hipEvent pair puts two ~6 us bubbles into the stream, 3.6 % of a C3 iteration)
+    # (sampled: a hipEvent pair puts two ~6 us bubbles into the stream, 3.6 % of a C3 iteration if every launch is bracketed)
     engine.prob.set_option(native.OPT_TIMING, 1 << dom_id)
-    engine.prob.set_option(native.OPT_TIMING_STRIDE, args.timing_stride)
+    stride = args.timing_stride if args.timing_stride > 0 else max(1, min(10, args.steps // 5))
+    engine.prob.set_option(native.OPT_TIMING_STRIDE, stride)
     engine.prob.reset_timing()
     sync()
     t0 = time.perf_counter()
@@ -252,7 +253,7 @@ def main():
             roofline.update(bound="lds", achieved=achieved, peak=LDS_ADD_PEAK_TADDS, unit="Tadd/s", frac=achieved / LDS_ADD_PEAK_TADDS)
     roofline["avg_launch_ms"] = dom_avg_ms
     roofline["launches"] = dom_n
-    roofline["launches_note"] = "hipEvent-bracketed launches of this kernel class: every %d-th of the timed region" % args.timing_stride
+    roofline["launches_note"] = "hipEvent-bracketed launches of this kernel class: every %d-th of the timed region" % stride
     # HBM bytes per launch from rocprofv3 --pmc passes (tools/parse_pmc.py), keyed by workload and kernel:
     # profiles/traffic.json = {"<workload key>": {"<kernel>": bytes, ...}}; null when no record matches this run
     workload_key = "%s/%dcams_%dpts_per_rank/%s" % (args.config, scene.n_cams, int(ptr_l.shape[0]) - 1, schur_kernel)
