@@ -117,14 +117,13 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps (sqrt / division expand to
-// ~50 dependent instructions each).
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed (5e-8) + ONE third-order step r (1 + e/2 + 3 e^2 / 8),
+// e = 1 - d r^2: five operations where two Newton steps take seven, and closer -- 1.4e-16 against 2.4e-16 maximal
+// relative error (tools/microbench_solve.hip).  (sqrt / division expand to ~50 dependent instructions each.)
 __device__ __forceinline__ double rsqrt_nr(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  const double h = 0.5 * d;
-  r = r * (1.5 - h * r * r);
-  r = r * (1.5 - h * r * r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-(d * r), r, 1.0);
+  return __builtin_fma(r, e * __builtin_fma(e, 0.375, 0.5), r);
 }
 
 // chol3_inv without sqrt or division: a = (a00,a10,a11,a20,a21,a22) SPD -> Li = L^-1 (lower, packed).
@@ -190,11 +189,11 @@ __device__ __forceinline__ double wave_lane0(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// 1/d: v_rcp_f64 seed (5e-8) + one third-order step r (1 + e + e^2), e = 1 - d r (1.1e-16; two Newton steps: 1.9e-16)
 __device__ __forceinline__ double rcp_nr(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = r * (2.0 - d * r);
-  r = r * (2.0 - d * r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 
 template <int N>

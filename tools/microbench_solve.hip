@@ -22,8 +22,14 @@ __global__ void k_precision(const double* in, double* out, int n) {
   const double r2 = r1 * (1.5 - h * r1 * r1);
   const double c0 = __builtin_amdgcn_rcp(d);
   const double c1 = c0 * (2.0 - d * c0);
-  out[6 * i + 0] = r0; out[6 * i + 1] = r1; out[6 * i + 2] = r2;
-  out[6 * i + 3] = c0; out[6 * i + 4] = c1; out[6 * i + 5] = c1 * (2.0 - d * c1);
+  out[8 * i + 0] = r0; out[8 * i + 1] = r1; out[8 * i + 2] = r2;
+  out[8 * i + 3] = c0; out[8 * i + 4] = c1; out[8 * i + 5] = c1 * (2.0 - d * c1);
+  // one third-order step instead of two Newton steps: r0 (1 + e/2 + 3 e^2 / 8), e = 1 - d r0^2 (five operations instead
+  // of seven); c0 (1 + e + e^2), e = 1 - d c0 (three instead of four)
+  const double e = __builtin_fma(-(d * r0), r0, 1.0);
+  out[8 * i + 6] = __builtin_fma(r0, e * __builtin_fma(e, 0.375, 0.5), r0);
+  const double f = __builtin_fma(-d, c0, 1.0);
+  out[8 * i + 7] = __builtin_fma(c0, __builtin_fma(f, f, f), c0);
 }
 
 // one wave; MODE selects the chain; returns cycles per link in out[0]
@@ -121,20 +127,23 @@ int main() {
       h[i] = std::exp((u - 0.5) * 40.0);      // 2e-9 .. 5e8
     }
     double *din, *dout;
-    CHECK(hipMalloc(&din, n * sizeof(double))); CHECK(hipMalloc(&dout, 6 * n * sizeof(double)));
+    CHECK(hipMalloc(&din, n * sizeof(double))); CHECK(hipMalloc(&dout, 8 * n * sizeof(double)));
     CHECK(hipMemcpy(din, h.data(), n * sizeof(double), hipMemcpyHostToDevice));
     k_precision<<<n / 256, 256>>>(din, dout, n);
-    std::vector<double> o(6 * (size_t)n);
+    std::vector<double> o(8 * (size_t)n);
     CHECK(hipMemcpy(o.data(), dout, o.size() * sizeof(double), hipMemcpyDeviceToHost));
-    double e[6] = {0, 0, 0, 0, 0, 0};
+    double e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
       const long double d = h[i];
       const long double rs = 1.0L / sqrtl(d), rc = 1.0L / d;
-      for (int k = 0; k < 3; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[6 * i + k] - rs) / rs));
-      for (int k = 3; k < 6; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[6 * i + k] - rc) / rc));
+      for (int k = 0; k < 3; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[8 * i + k] - rs) / rs));
+      for (int k = 3; k < 6; ++k) e[k] = std::fmax(e[k], (double)fabsl((o[8 * i + k] - rc) / rc));
+      e[6] = std::fmax(e[6], (double)fabsl((o[8 * i + 6] - rs) / rs));
+      e[7] = std::fmax(e[7], (double)fabsl((o[8 * i + 7] - rc) / rc));
     }
     printf("v_rsq_f64 max rel err: seed %.3e  +1 Newton %.3e  +2 Newton %.3e\n", e[0], e[1], e[2]);
     printf("v_rcp_f64 max rel err: seed %.3e  +1 Newton %.3e  +2 Newton %.3e\n", e[3], e[4], e[5]);
+    printf("one third-order step: rsq %.3e  rcp %.3e\n", e[6], e[7]);
   }
   // ---- 2. chains ----
   {
