@@ -810,7 +810,10 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
     const int lo = std::max(0, hi - gsize);
     ba_back_solve_kernel<<<1, BS_THREADS, 0, s>>>(d, p->cur, hi, lo);
     if (lo > 0) {
-      const int slices = (p->deterministic || hi - lo <= 16) ? 1 : std::min(4, (hi - lo + 15) / 16 + 1);
+      // one slice = one writer per output, no atomics: also whenever a caller's reduced buffer is bound, i.e. the
+      // multi-GPU mode, where every rank repeats this solve and all of them must end on bit-identical cameras
+      const bool replicated = p->dev.red != p->own_red;
+      const int slices = (p->deterministic || replicated || hi - lo <= 16) ? 1 : std::min(4, (hi - lo + 15) / 16 + 1);
       ba_back_update_kernel<<<dim3(lo, slices), 256, 0, s>>>(d, lo, hi);
     }
     hi = lo;
