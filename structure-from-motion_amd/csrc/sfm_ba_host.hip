@@ -206,7 +206,7 @@ static int ba_alloc_problem(int V, int N, long long M, hipStream_t stream, sfm_b
   BA_ALLOC(p->own_red, red_size(d.nbk));
   BA_ALLOC(d.delta, (size_t)d.nbk * kNB);
   BA_ALLOC(d.ldiag, (size_t)((d.P + 31) / 32) * 32 * 32);
-  BA_ALLOC(d.xinv, red_rhs_off(d.nbk));
+  BA_ALLOC(d.xinv, d.nbk <= kInvRowsMaxNbk ? red_rhs_off(d.nbk) : 1);      // beyond that the back substitution runs block row by block row
   BA_ALLOC(d.sync_ctr, 1);
   BA_ALLOC(d.status, 2);
   BA_ALLOC(d.sinfo, 4);

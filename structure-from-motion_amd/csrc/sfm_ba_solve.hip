@@ -550,7 +550,6 @@ __global__ void ba_symmetrize_kernel(const double* __restrict__ red, int P, doub
 // The workgroup that finishes last (release / acquire through a device counter) does the camera update of
 // ba:383-392 and prepares the next iteration's cameras: 8.0 us in all at V = 50 against 4.8 + 5.0 us with the camera
 // update as its own launch (12.4 against 7.4 + 4.2 at V = 200).
-constexpr int kInvRowsMaxNbk = 52;
 constexpr int IA_THREADS = 1024;      // 32 rows x 32 slices of block columns
 __global__ __launch_bounds__(IA_THREADS) void ba_inv_apply_kernel(BaDev d, int cur) {
   __shared__ double part[IA_THREADS / 32][NB + 1];
