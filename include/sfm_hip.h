@@ -74,7 +74,9 @@ extern "C" {
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
-#define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA: the product kernel the next iteration launches */
+#define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA / SFM_SCHUR_ROWS: the product kernel the next iteration launches
+                                   * (asking builds the row-panel product's work split if that is the candidate, so the answer is
+                                   * the kernel that will run, not the one that was hoped for) */
 #define SFM_INFO_UPLOAD_BYTES  2  /* host -> device bytes moved on behalf of this handle since sfm_ba_create */
 #define SFM_INFO_N_CAMS        3
 #define SFM_INFO_N_PTS         4
@@ -105,6 +107,11 @@ int sfm_synchronize(void);
  * two 4 KB zones of 0xA5 that are checked (after a device-wide synchronise) whenever the buffer goes back to the pool;
  * a kernel that wrote outside its buffer aborts the process with a message.  For test runs only. */
 int sfm_pool_redzone_active(void);
+/* Diagnostic: pool mode bits (1 = SFM_POOL_REDZONE, 2 = SFM_POOL_GUARD: every device buffer is its own virtual-memory
+ * mapping that ends where the buffer ends, followed by a reserved, unmapped granule -- an out-of-bounds READ past the end
+ * faults at the access; one test pass on the GPU box runs under it).  *tail_slack = mapped bytes behind a probe buffer of
+ * probe_bytes (guard mode: < 16; -1 before sfm_init), *guard_allocs = buffers handed out in guard mode so far. */
+int sfm_pool_mode(int64_t probe_bytes, int64_t* tail_slack, int64_t* guard_allocs);
 const char* sfm_last_error(void);
 
 /* ---- unit-level helpers (parity hooks; batched) ------------------------------------------------ */
@@ -148,6 +155,27 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets /*[n_views+1]*/, int
                             const double* C0 /*[n_views][3]*/, double lambda, int iters, int quirks,
                             double* R_out /*[n_views][9]*/, double* C_out /*[n_views][3]*/,
                             int* status /*[n_views]*/);
+
+/* ---- DEVICE-pointer, stream-ordered forms of the calls above ---------------------------------------------- */
+/* Same kernels, same layouts, but every pointer is DEVICE memory, the work is only ENQUEUED on `hip_stream`
+ * (hipStream_t as void*; NULL = the library stream) and the call returns without synchronising: the per-view loop of
+ * the reference (PnP at ba_processor.py:191, triangulate at :246, BA at :267) can chain them on one stream around a
+ * resident BA problem.  d_status of the PnP form is read by the caller after its own synchronisation
+ * (SFM_OK / SFM_E_BAD_ROTATION / SFM_E_QW_ZERO / SFM_E_SQRT_DOMAIN per view).  d_X_out may equal d_X_in. */
+int sfm_tri_nonlinear_dev(int m, int n_views, const double* d_projs /*[n_views][3][4]*/, const double* d_uv /*[n_views][2][m]*/,
+                          const double* d_X_in /*[4][m]*/, double lambda, int iters, double* d_X_out /*[4][m]*/, void* hip_stream);
+int sfm_tri_linear_dev(int m, int n_views, const double* d_projs, const double* d_uv, double* d_X_out /*[4][m]*/, void* hip_stream);
+int sfm_triangulate_dev(int m, int n_views, const double* d_projs, const double* d_uv, double lambda, int iters,
+                        double* d_X_out /*[4][m]*/, void* hip_stream);
+int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets /*[n_views+1]*/, int total, const double* d_uv_pix /*[3][total]*/,
+                                const double* d_X /*[4][total]*/, const double* d_K /*[n_views][9]*/, const double* d_R0 /*[n_views][9]*/,
+                                const double* d_C0 /*[n_views][3]*/, double lambda, int iters, int quirks,
+                                double* d_R_out /*[n_views][9]*/, double* d_C_out /*[n_views][3]*/, int* d_status /*[n_views]*/,
+                                void* hip_stream);
+/* X_out[4][n] = (px, py, pz, 1)[index[i]]: the 2D-3D association of ba_processor.py:184-188 (np.take of tri_pts) for points
+ * that already live on the device (sfm_ba_points_ptr), so that the per-view PnP uploads keys and indices only. */
+int sfm_gather_points_dev(int n, const int* d_index /*[n]*/, const double* d_px, const double* d_py, const double* d_pz,
+                          double* d_X_out /*[4][n]*/, void* hip_stream);
 
 /* ---- CamposeProcessor.linear_estimate_cam_pose_pnp (campose_processor.py:249-305, 485-633) ----------- */
 /* RANSAC over 6-point DLT hypotheses.  The caller draws the n_hyp six-point samples (the reference uses
@@ -252,6 +280,10 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams /*[n_new
  * synchronises.  *launches may be NULL. */
 int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches);
 int sfm_ba_reset_timing(sfm_ba_problem* p);
+/* Calibration of those brackets: the average hipEvent-to-hipEvent time around a kernel that does nothing, on the
+ * problem's stream, between other launches (n samples).  A bracket reads the kernel's duration PLUS this (the events'
+ * own stream bubbles); bench.py subtracts it, less the ~1.5 us an empty kernel itself takes.  Synchronises. */
+int sfm_ba_event_overhead(sfm_ba_problem* p, int n, double* avg_ms);
 /* Diagnostic: shader-clock stamps written by instrumented kernels when SFM_OPT_DEBUG has bit 8 set. */
 int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n);
 
@@ -268,6 +300,11 @@ int sfm_ba_solve_update(sfm_ba_problem* p, double lambda, int quirks);
  * reads or replaces the state completes it first; a loop that only times linearize_reduce / solve_update calls ends
  * with sfm_ba_flush so that its last iteration is complete as well.  Enqueues only. */
 int sfm_ba_flush(sfm_ba_problem* p);
+/* DEVICE pointers of the resident points (SoA, n_pts doubles each) and the stream the problem runs on: the current
+ * state after everything enqueued so far (a deferred back substitution is enqueued first).  Valid until the next
+ * sfm_ba_append / sfm_ba_destroy. */
+int sfm_ba_points_ptr(sfm_ba_problem* p, void** d_px, void** d_py, void** d_pz, int* n_pts);
+int sfm_ba_stream(sfm_ba_problem* p, void** hip_stream);
 /* DEVICE pointer + element count of the contiguous reduced buffer (doubles). */
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld);
 /* Bind an externally owned DEVICE buffer (e.g. a torch tensor) as the reduced buffer. */

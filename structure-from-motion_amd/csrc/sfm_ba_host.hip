@@ -345,7 +345,22 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
   SFM_TRY(check_problem(p));
   if (value == nullptr) { set_error("sfm_ba_info: value is null"); return SFM_E_SHAPE; }
   switch (what) {
-    case SFM_INFO_SCHUR_KERNEL: *value = ba_schur_choice(p); return SFM_OK;
+    case SFM_INFO_SCHUR_KERNEL: {
+      // the kernel the next iteration WILL launch: the row-panel product needs its camera-major list and work split,
+      // which decide whether it can run at all -- build them now rather than answer "rows" and then launch "pairs"
+      int choice = ba_schur_choice(p);
+      if (choice == SFM_SCHUR_ROWS && p->dev.M > 0 && p->dev.N > 0) {
+        if (!p->rows_built) {
+          SFM_TRY(ba_flush(p));
+          SFM_TRY(ba_rows_enqueue_build(p));
+          SFM_TRY(ba_rows_plan(p));
+          p->rows_built = true;
+        }
+        if (!p->rows_ok) choice = SFM_SCHUR_PAIRS;
+      }
+      *value = choice;
+      return SFM_OK;
+    }
     case SFM_INFO_UPLOAD_BYTES: *value = p->upload_bytes; return SFM_OK;
     case SFM_INFO_N_CAMS: *value = p->dev.V; return SFM_OK;
     case SFM_INFO_N_PTS: *value = p->dev.N; return SFM_OK;
@@ -529,6 +544,9 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   std::swap(p->rows_R, q->rows_R); std::swap(p->rows_tpr, q->rows_tpr); std::swap(p->rows_wgs, q->rows_wgs);
   std::swap(p->rows_groups, q->rows_groups);
   std::swap(p->max_track, q->max_track);
+  // deterministic mode holds for the grown scene only while the dense product fits and the camera accumulators stay in
+  // LDS (V <= 234): beyond that the handle falls back to the default path instead of mixing the two reduce kernels
+  p->deterministic = q->deterministic;
   // an externally bound reduced buffer has the wrong size when cameras were added: the library's own buffer takes
   // over and the caller binds a new one (sfm_ba_reduced_buffer reports the new size); with the camera count
   // unchanged the binding survives
@@ -538,6 +556,22 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   p->cur = 0; p->prep_valid = false; p->red_clean = false; p->lin_rows = 0;
   std::swap(p->dev.stamps, q->dev.stamps);      // the diagnostic stamp buffer stays with the handle
   return sfm_ba_destroy(q);
+}
+
+int sfm_ba_points_ptr(sfm_ba_problem* p, void** d_px, void** d_py, void** d_pz, int* n_pts) {
+  SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));           // the deferred back substitution still has to move the points
+  if (d_px) *d_px = p->dev.px;
+  if (d_py) *d_py = p->dev.py;
+  if (d_pz) *d_pz = p->dev.pz;
+  if (n_pts) *n_pts = p->dev.N;
+  return SFM_OK;
+}
+
+int sfm_ba_stream(sfm_ba_problem* p, void** hip_stream) {
+  SFM_TRY(check_problem(p));
+  if (hip_stream) *hip_stream = p->stream;
+  return SFM_OK;
 }
 
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld) {
@@ -573,6 +607,34 @@ int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* 
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = t.used;
+  return SFM_OK;
+}
+
+namespace sfm { __global__ void ba_noop_kernel() {} }
+
+int sfm_ba_event_overhead(sfm_ba_problem* p, int n, double* avg_ms) {
+  SFM_TRY(check_problem(p));
+  if (n < 1 || avg_ms == nullptr) { set_error("sfm_ba_event_overhead: bad arguments"); return SFM_E_SHAPE; }
+  hipStream_t s = p->stream;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev((size_t)n);
+  for (auto& e : ev) { SFM_HIP(hipEventCreate(&e.first)); SFM_HIP(hipEventCreate(&e.second)); }
+  // the same pattern ba_tick brackets a kernel class with, around a kernel that does nothing, between other work
+  for (auto& e : ev) {
+    ba_noop_kernel<<<1, 64, 0, s>>>();
+    SFM_HIP(hipEventRecord(e.first, s));
+    ba_noop_kernel<<<1, 64, 0, s>>>();
+    SFM_HIP(hipEventRecord(e.second, s));
+    ba_noop_kernel<<<1, 64, 0, s>>>();
+  }
+  SFM_HIP(hipStreamSynchronize(s));
+  double tot = 0;
+  for (auto& e : ev) {
+    float ms = 0;
+    SFM_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+    tot += ms;
+    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+  }
+  *avg_ms = tot / n;
   return SFM_OK;
 }
 

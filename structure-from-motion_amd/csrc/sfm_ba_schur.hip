@@ -698,7 +698,7 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
   const int tile_blocks = (ntiles * RB * RB + 255) / 256;
   const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
   ba_tick(p, SFM_K_REDUCE, true, s);
-  if (p->deterministic) ba_schur_reduce_det_kernel<<<tile_blocks + (d.P + 255) / 256 + 1, 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows, p->lin_grid);
+  if (p->deterministic && p->lin_rows > 0) ba_schur_reduce_det_kernel<<<tile_blocks + (d.P + 255) / 256 + 1, 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows, p->lin_grid);
   else ba_schur_reduce_kernel<<<dim3(tile_blocks + cam_blocks + 1, 4), 256, 0, s>>>(d, ws, pl, tile_blocks, p->lin_rows, p->lin_grid);
   ba_tick(p, SFM_K_REDUCE, false, s);
   SFM_HIP(hipGetLastError());

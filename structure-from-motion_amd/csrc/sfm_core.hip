@@ -55,14 +55,26 @@ int ensure_init() {
 
 // ---------------------------------------------------------------------------------------------
 // device-memory pool (see sfm_common.h)
+//
+// Three process-wide modes, chosen by the environment at first use:
+//   default            blocks rounded up to a power of two, cached per size class.  NO slack behind a buffer: a read past
+//                      the end is not made harmless by construction (SFM_POOL_SLACK=<bytes> adds that many bytes behind
+//                      every block -- a field switch for a suspected stray read, never set by the tests).
+//   SFM_POOL_REDZONE=1 every buffer between two 4 KB zones of 0xA5, checked when it returns to the pool: an out-of-bounds
+//                      WRITE aborts with a message.
+//   SFM_POOL_GUARD=1   every buffer is its own virtual-memory mapping (hipMemAddressReserve / hipMemCreate / hipMemMap)
+//                      that ENDS (to 16 bytes) where the buffer ends, followed by a reserved, never mapped granule: an
+//                      out-of-bounds READ or write past the end faults at the access instead of landing in a neighbour.
+//                      No caching (every free unmaps).  For one test pass on the GPU box.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct Block { void* base; size_t size; size_t bytes; };    // hipMalloc'ed block, rounded size, bytes the caller asked for
+struct Block { void* base; size_t size; size_t bytes; hipMemGenericAllocationHandle_t handle; size_t mapped; };
 struct Pool {
   std::mutex mu;
   std::unordered_map<void*, Block> live;                  // pointer handed out -> its block
   std::unordered_map<size_t, std::vector<void*>> free_by_size;   // rounded size -> cached block bases
   size_t cached_bytes = 0;
+  long long guard_allocs = 0;
 };
 Pool& pool() {
   static Pool p;
@@ -74,13 +86,22 @@ size_t round_up_pow2(size_t n) {
   return r;
 }
 constexpr size_t kPoolCap = (size_t)2 << 30;
-// SFM_POOL_REDZONE=1 (tests): every buffer sits between two 4 KB zones filled with 0xA5; pool_free waits for the
-// device, reads them back and aborts with a message if a kernel wrote outside its buffer.  Out-of-bounds READS stay
-// invisible to it (their values are discarded by construction or they would show up as parity failures).
 constexpr size_t kRedZone = 4096;
+bool env_is_one(const char* name) {
+  const char* e = std::getenv(name);
+  return e && e[0] == '1';
+}
 bool redzone_on() {
-  static const bool on = [] { const char* e = std::getenv("SFM_POOL_REDZONE"); return e && e[0] == '1'; }();
+  static const bool on = env_is_one("SFM_POOL_REDZONE");
   return on;
+}
+bool guard_on() {
+  static const bool on = env_is_one("SFM_POOL_GUARD");
+  return on;
+}
+size_t slack_bytes() {
+  static const size_t n = [] { const char* e = std::getenv("SFM_POOL_SLACK"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+  return n;
 }
 void redzone_fill(const Block& b, void* user) {
   char* base = static_cast<char*>(b.base);
@@ -105,14 +126,74 @@ void redzone_check(const Block& b, void* user) {
   scan("BEFORE", base, kRedZone);
   scan("PAST THE END OF", end, tail);
 }
+
+// ---- guard mode --------------------------------------------------------------------------------
+size_t guard_granularity(int device) {
+  static size_t g = 0;
+  if (g) return g;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) gran = (size_t)2 << 20;
+  g = gran;
+  return g;
+}
+hipError_t guard_alloc(void** ptr, size_t bytes, Block* out) {
+  const int device = ctx().device < 0 ? 0 : ctx().device;
+  const size_t gran = guard_granularity(device);
+  const size_t need = (std::max<size_t>(bytes, 1) + 15) & ~(size_t)15;      // vector loads are at most 16 bytes wide
+  const size_t mapped = (need + gran - 1) / gran * gran;
+  void* base = nullptr;
+  hipError_t e = hipMemAddressReserve(&base, mapped + gran, gran, nullptr, 0);      // + one granule that is never mapped
+  if (e != hipSuccess) return e;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  hipMemGenericAllocationHandle_t h{};
+  e = hipMemCreate(&h, mapped, &prop, 0);
+  if (e != hipSuccess) { (void)hipMemAddressFree(base, mapped + gran); return e; }
+  e = hipMemMap(base, mapped, 0, h, 0);
+  if (e != hipSuccess) { (void)hipMemRelease(h); (void)hipMemAddressFree(base, mapped + gran); return e; }
+  hipMemAccessDesc acc{};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = device;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(base, mapped, &acc, 1);
+  if (e != hipSuccess) { (void)hipMemUnmap(base, mapped); (void)hipMemRelease(h); (void)hipMemAddressFree(base, mapped + gran); return e; }
+  *ptr = static_cast<char*>(base) + (mapped - need);      // the buffer ends where the mapping ends
+  *out = Block{base, mapped + gran, bytes, h, mapped};
+  return hipSuccess;
+}
+void guard_free(const Block& b) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(b.base, b.mapped);
+  (void)hipMemRelease(b.handle);
+  (void)hipMemAddressFree(b.base, b.size);
+}
 }  // namespace
 
 hipError_t pool_alloc(void** ptr, size_t bytes) {
-  const bool rz = redzone_on();
-  // 4 KB of slack behind every buffer even without the red zones: a read a little past the end (an idle lane's
-  // address) then lands in memory the library owns instead of on an unmapped page
-  const size_t sz = round_up_pow2(bytes + (rz ? 2 * kRedZone : kRedZone));
   Pool& P = pool();
+  if (guard_on()) {
+    Block b{};
+    const hipError_t e = guard_alloc(ptr, bytes, &b);
+    if (e != hipSuccess) {
+      std::fprintf(stderr, "sfm pool guard mode: the virtual-memory API failed (%s); SFM_POOL_GUARD cannot be honoured on this stack\n", hipGetErrorString(e));
+      std::abort();      // a test pass that silently ran unguarded would claim what it did not check
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[*ptr] = b;
+    ++P.guard_allocs;
+    return hipSuccess;
+  }
+  const bool rz = redzone_on();
+  // size class = the request rounded up to a power of two; red zones / optional slack come on top of the class, so a
+  // request that already is a power of two does not double
+  const size_t cls = round_up_pow2(bytes);
+  const size_t sz = cls + (rz ? 2 * kRedZone : slack_bytes());
   void* base = nullptr;
   {
     std::lock_guard<std::mutex> g(P.mu);
@@ -132,7 +213,7 @@ hipError_t pool_alloc(void** ptr, size_t bytes) {
     if (e != hipSuccess) return e;
   }
   *ptr = rz ? static_cast<char*>(base) + kRedZone : base;
-  const Block b{base, sz, bytes};
+  const Block b{base, sz, bytes, {}, 0};
   if (rz) redzone_fill(b, *ptr);
   std::lock_guard<std::mutex> g(P.mu);
   P.live[*ptr] = b;
@@ -150,6 +231,7 @@ void pool_free(void* ptr) {
     b = it->second;
     P.live.erase(it);
   }
+  if (b.mapped) { guard_free(b); return; }
   if (redzone_on()) redzone_check(b, ptr);
   {
     std::lock_guard<std::mutex> g(P.mu);
@@ -169,6 +251,30 @@ void pool_release_all() {
     for (void* q : kv.second) (void)hipFree(q);
   P.free_by_size.clear();
   P.cached_bytes = 0;
+}
+
+// Diagnostics of the pool mode (sfm_pool_mode): bit 0 red zones, bit 1 guard mappings; *tail_slack = bytes between the
+// end of a probe buffer of `probe_bytes` and the end of what is mapped behind it (guard mode: < 16).
+int pool_mode_probe(size_t probe_bytes, long long* tail_slack, long long* guard_allocs) {
+  int mode = (redzone_on() ? 1 : 0) | (guard_on() ? 2 : 0);
+  if (tail_slack) {
+    *tail_slack = -1;
+    if (ctx().inited) {
+      void* q = nullptr;
+      if (pool_alloc(&q, probe_bytes) == hipSuccess) {
+        Pool& P = pool();
+        {
+          std::lock_guard<std::mutex> g(P.mu);
+          const Block& b = P.live[q];
+          const char* end_mapped = static_cast<char*>(b.base) + (b.mapped ? b.mapped : b.size);
+          *tail_slack = (long long)(end_mapped - (static_cast<char*>(q) + probe_bytes));
+        }
+        pool_free(q);
+      }
+    }
+  }
+  if (guard_allocs) *guard_allocs = pool().guard_allocs;
+  return mode;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -754,6 +860,24 @@ __global__ void pnp_inlier_mask_kernel(int n, const double* __restrict__ proj, c
   mask[i] = pnp_is_inlier(P, uv_pix, X, n, i, threshold) ? 1 : 0;
 }
 
+// Columns [4][n] (X, Y, Z, 1) of the points index[0..n) of SoA point arrays (e.g. a resident BA problem's, sfm_ba_points_ptr):
+// what the per-view PnP of the incremental loop consumes (ba_processor.py:184-191), built without a host round trip.
+__global__ void gather_points_kernel(int n, const int* __restrict__ index, const double* __restrict__ px,
+                                     const double* __restrict__ py, const double* __restrict__ pz, double* __restrict__ X) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = index[i];
+  X[i] = px[p]; X[(size_t)n + i] = py[p]; X[2 * (size_t)n + i] = pz[p]; X[3 * (size_t)n + i] = 1.0;
+}
+
+static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
+                                 const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
+                                 double* R_out, double* C_out, int* status, hipStream_t s) {
+  pnp_nonlinear_kernel<<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
+  SFM_HIP(hipGetLastError());
+  return SFM_OK;
+}
+
 static int first_bad(const std::vector<int>& st) {
   for (size_t i = 0; i < st.size(); ++i)
     if (st[i] != SFM_OK) return st[i];
@@ -831,6 +955,14 @@ int sfm_synchronize(void) {
 
 int sfm_pool_redzone_active(void) { return redzone_on() ? 1 : 0; }
 
+int sfm_pool_mode(int64_t probe_bytes, int64_t* tail_slack, int64_t* guard_allocs) {
+  long long slack = -1, allocs = 0;
+  const int mode = pool_mode_probe(probe_bytes > 0 ? (size_t)probe_bytes : 1, tail_slack ? &slack : nullptr, &allocs);
+  if (tail_slack) *tail_slack = slack;
+  if (guard_allocs) *guard_allocs = allocs;
+  return mode;
+}
+
 int sfm_quat_to_rot(int n, const double* q, double* R, int* status) {
   SFM_TRY(ensure_init());
   if (n < 0) { set_error("sfm_quat_to_rot: n < 0"); return SFM_E_SHAPE; }
@@ -886,6 +1018,82 @@ int sfm_jac_pt(int n, int n_views, const double* projs, const double* X, double*
   SFM_HIP(hipGetLastError());
   SFM_TRY(dJ.download(Jx, 6 * (size_t)n * n_views, s));
   SFM_TRY(stream_sync(s));
+  return SFM_OK;
+}
+
+// ---- DEVICE-pointer, stream-ordered forms: enqueue on the caller's stream and return ---------------------------
+static hipStream_t pick_stream(void* hip_stream) { return hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx().stream; }
+
+int sfm_tri_nonlinear_dev(int m, int n_views, const double* d_projs, const double* d_uv, const double* d_X_in, double lambda,
+                          int iters, double* d_X_out, void* hip_stream) {
+  SFM_TRY(ensure_init());
+  if (m < 0 || n_views < 1 || iters < 0) {
+    set_error("sfm_tri_nonlinear_dev: bad sizes m=%d n_views=%d iters=%d", m, n_views, iters);
+    return SFM_E_SHAPE;
+  }
+  if (m == 0) return SFM_OK;
+  if (!d_projs || !d_uv || !d_X_in || !d_X_out) { set_error("sfm_tri_nonlinear_dev: null device pointer"); return SFM_E_SHAPE; }
+  const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
+  launch_tri_nonlinear(m, n_views, d_projs, d_uv, d_X_in, lambda, iters, d_X_out, lds, pick_stream(hip_stream));
+  SFM_HIP(hipGetLastError());
+  return SFM_OK;
+}
+
+int sfm_tri_linear_dev(int m, int n_views, const double* d_projs, const double* d_uv, double* d_X_out, void* hip_stream) {
+  SFM_TRY(ensure_init());
+  if (m < 0 || n_views < 1) { set_error("sfm_tri_linear_dev: bad sizes m=%d n_views=%d", m, n_views); return SFM_E_SHAPE; }
+  if (m == 0) return SFM_OK;
+  if (!d_projs || !d_uv || !d_X_out) { set_error("sfm_tri_linear_dev: null device pointer"); return SFM_E_SHAPE; }
+  const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
+  tri_linear_kernel<<<(m + 255) / 256, 256, lds, pick_stream(hip_stream)>>>(m, n_views, d_projs, d_uv, d_X_out);
+  SFM_HIP(hipGetLastError());
+  return SFM_OK;
+}
+
+int sfm_triangulate_dev(int m, int n_views, const double* d_projs, const double* d_uv, double lambda, int iters,
+                        double* d_X_out, void* hip_stream) {
+  SFM_TRY(ensure_init());
+  if (m < 0 || n_views < 1 || iters < 0) {
+    set_error("sfm_triangulate_dev: bad sizes m=%d n_views=%d iters=%d", m, n_views, iters);
+    return SFM_E_SHAPE;
+  }
+  if (m == 0) return SFM_OK;
+  if (!d_projs || !d_uv || !d_X_out) { set_error("sfm_triangulate_dev: null device pointer"); return SFM_E_SHAPE; }
+  hipStream_t s = pick_stream(hip_stream);
+  const size_t lds = n_views <= kTriLdsViews ? sizeof(double) * 12 * n_views : 0;
+  // the DLT result lands in X_out and is refined in place: a thread reads and writes only its own point
+  tri_linear_kernel<<<(m + 255) / 256, 256, lds, s>>>(m, n_views, d_projs, d_uv, d_X_out);            // tri:85
+  launch_tri_nonlinear(m, n_views, d_projs, d_uv, d_X_out, lambda, iters, d_X_out, lds, s);           // tri:86
+  SFM_HIP(hipGetLastError());
+  return SFM_OK;
+}
+
+int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, const double* d_uv_pix, const double* d_X,
+                                const double* d_K, const double* d_R0, const double* d_C0, double lambda, int iters,
+                                int quirks, double* d_R_out, double* d_C_out, int* d_status, void* hip_stream) {
+  SFM_TRY(ensure_init());
+  if (n_views < 0 || total < 0 || iters < 0) {
+    set_error("sfm_pnp_nonlinear_batch_dev: bad sizes n_views=%d total=%d iters=%d", n_views, total, iters);
+    return SFM_E_SHAPE;
+  }
+  if (n_views == 0) return SFM_OK;
+  if (!d_offsets || !d_K || !d_R0 || !d_C0 || !d_R_out || !d_C_out || !d_status || (total > 0 && (!d_uv_pix || !d_X))) {
+    set_error("sfm_pnp_nonlinear_batch_dev: null device pointer");
+    return SFM_E_SHAPE;
+  }
+  SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
+                                d_C_out, d_status, pick_stream(hip_stream)));
+  return SFM_OK;
+}
+
+int sfm_gather_points_dev(int n, const int* d_index, const double* d_px, const double* d_py, const double* d_pz,
+                          double* d_X_out, void* hip_stream) {
+  SFM_TRY(ensure_init());
+  if (n < 0) { set_error("sfm_gather_points_dev: n < 0"); return SFM_E_SHAPE; }
+  if (n == 0) return SFM_OK;
+  if (!d_index || !d_px || !d_py || !d_pz || !d_X_out) { set_error("sfm_gather_points_dev: null device pointer"); return SFM_E_SHAPE; }
+  gather_points_kernel<<<(n + 255) / 256, 256, 0, pick_stream(hip_stream)>>>(n, d_index, d_px, d_py, d_pz, d_X_out);
+  SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
 
@@ -1034,9 +1242,8 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   SFM_TRY(dK.upload(K, 9 * (size_t)n_views, s)); SFM_TRY(dR0.upload(R0, 9 * (size_t)n_views, s));
   SFM_TRY(dC0.upload(C0, 3 * (size_t)n_views, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_views)); SFM_TRY(dC.alloc(3 * (size_t)n_views)); SFM_TRY(dSt.alloc(n_views));
-  pnp_nonlinear_kernel<<<n_views, 256, 0, s>>>(dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks,
-                                               dR.p, dC.p, dSt.p);
-  SFM_HIP(hipGetLastError());
+  SFM_TRY(enqueue_pnp_nonlinear(n_views, dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p,
+                                dSt.p, s));
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
   SFM_TRY(stream_sync(s));

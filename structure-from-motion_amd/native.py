@@ -36,6 +36,8 @@ EXPORTS = (
     "sfm_pool_redzone_active", "sfm_ba_iterate", "sfm_ba_get_state", "sfm_ba_append", "sfm_ba_kernel_time", "sfm_ba_reset_timing", "sfm_ba_debug_stamps",
     "sfm_ba_linearize_reduce", "sfm_ba_solve_update", "sfm_ba_reduced_buffer",
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
+    "sfm_pool_mode", "sfm_tri_nonlinear_dev", "sfm_tri_linear_dev", "sfm_triangulate_dev", "sfm_pnp_nonlinear_batch_dev",
+    "sfm_gather_points_dev", "sfm_ba_points_ptr", "sfm_ba_stream", "sfm_ba_event_overhead",
 )
 
 _lib = None
@@ -113,6 +115,17 @@ def load():
     lib.sfm_essential_from_fundamental.argtypes = [_dp, _dp, _dp, _dp]
     lib.sfm_pose_candidates.argtypes = [_dp, _dp, _dp]
     lib.sfm_cheirality.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _ip, _ip, _ip]
+    vp = ctypes.c_void_p
+    lib.sfm_pool_mode.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    lib.sfm_tri_nonlinear_dev.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp]
+    lib.sfm_tri_linear_dev.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+    lib.sfm_triangulate_dev.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp]
+    lib.sfm_pnp_nonlinear_batch_dev.argtypes = [ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int,
+                                                ctypes.c_int, vp, vp, vp, vp]
+    lib.sfm_gather_points_dev.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    lib.sfm_ba_points_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), _ip]
+    lib.sfm_ba_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.sfm_ba_event_overhead.argtypes = [vp, ctypes.c_int, _dp]
     _lib = lib
     return lib
 
@@ -170,6 +183,43 @@ def synchronize():
 def pool_redzone_active():
     """True when the process runs with SFM_POOL_REDZONE=1 (device buffers between checked guard zones; tests only)."""
     return bool(load().sfm_pool_redzone_active())
+
+
+def pool_mode(probe_bytes=1000):
+    """(mode bits, mapped bytes behind a probe buffer, guard-mode allocations so far): bit 0 = SFM_POOL_REDZONE,
+    bit 1 = SFM_POOL_GUARD (every buffer ends at the end of its own mapping, the next page is unmapped)."""
+    slack = ctypes.c_int64(); allocs = ctypes.c_int64()
+    mode = load().sfm_pool_mode(int(probe_bytes), ctypes.byref(slack), ctypes.byref(allocs))
+    return mode, int(slack.value), int(allocs.value)
+
+
+# ---- device-pointer, stream-ordered forms (pointers as integers, e.g. torch.Tensor.data_ptr()) ------------------
+def _vp(ptr):
+    return ctypes.c_void_p(int(ptr)) if ptr else None
+
+
+def tri_nonlinear_dev(m, n_views, d_projs, d_uv, d_x_in, lam, iters, d_x_out, stream=0):
+    check(load().sfm_tri_nonlinear_dev(int(m), int(n_views), _vp(d_projs), _vp(d_uv), _vp(d_x_in), float(lam), int(iters),
+                                       _vp(d_x_out), _vp(stream)))
+
+
+def tri_linear_dev(m, n_views, d_projs, d_uv, d_x_out, stream=0):
+    check(load().sfm_tri_linear_dev(int(m), int(n_views), _vp(d_projs), _vp(d_uv), _vp(d_x_out), _vp(stream)))
+
+
+def triangulate_dev(m, n_views, d_projs, d_uv, lam, iters, d_x_out, stream=0):
+    check(load().sfm_triangulate_dev(int(m), int(n_views), _vp(d_projs), _vp(d_uv), float(lam), int(iters), _vp(d_x_out), _vp(stream)))
+
+
+def pnp_nonlinear_batch_dev(n_views, d_offsets, total, d_uv_pix, d_x, d_k, d_r0, d_c0, lam, iters, quirks, d_r_out, d_c_out,
+                            d_status, stream=0):
+    check(load().sfm_pnp_nonlinear_batch_dev(int(n_views), _vp(d_offsets), int(total), _vp(d_uv_pix), _vp(d_x), _vp(d_k), _vp(d_r0),
+                                             _vp(d_c0), float(lam), int(iters), int(quirks), _vp(d_r_out), _vp(d_c_out),
+                                             _vp(d_status), _vp(stream)))
+
+
+def gather_points_dev(n, d_index, d_px, d_py, d_pz, d_x_out, stream=0):
+    check(load().sfm_gather_points_dev(int(n), _vp(d_index), _vp(d_px), _vp(d_py), _vp(d_pz), _vp(d_x_out), _vp(stream)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -466,6 +516,19 @@ class BaProblem:
         self.n_pts += pts_new.shape[1]
         self.n_obs += obs_cam.shape[0]
 
+    def points_ptr(self):
+        """Device pointers (px, py, pz) of the resident points and their count (sfm_ba_points_ptr)."""
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        n = ctypes.c_int()
+        check(self._lib.sfm_ba_points_ptr(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(n)))
+        return a.value, b.value, c.value, n.value
+
+    def stream_ptr(self):
+        """The HIP stream this problem runs on (hipStream_t as an integer; sfm_ba_stream)."""
+        s = ctypes.c_void_p()
+        check(self._lib.sfm_ba_stream(self._h, ctypes.byref(s)))
+        return s.value or 0
+
     def reduced_buffer(self):
         ptr = ctypes.c_void_p(); n = ctypes.c_int64(); ld = ctypes.c_int()
         check(self._lib.sfm_ba_reduced_buffer(self._h, ctypes.byref(ptr), ctypes.byref(n), ctypes.byref(ld)))
@@ -478,6 +541,12 @@ class BaProblem:
         ms = ctypes.c_double(); n = ctypes.c_int()
         check(self._lib.sfm_ba_kernel_time(self._h, kernel_id, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def event_overhead(self, n=20):
+        """Average hipEvent bracket (ms) around an empty kernel on this problem's stream (sfm_ba_event_overhead)."""
+        ms = ctypes.c_double()
+        check(self._lib.sfm_ba_event_overhead(self._h, int(n), ctypes.byref(ms)))
+        return ms.value
 
     def reset_timing(self):
         check(self._lib.sfm_ba_reset_timing(self._h))

@@ -392,10 +392,19 @@ class HipBaMixin:
             else:
                 # points the caller did not touch since the last write-back are already on the device (bit for
                 # bit what get_state returned); appended points went up with sfm_ba_append
-                if done and not np.array_equal(init_tri_pts[:, :done], scene.pts_written[:, :done]):
+                if scene.pts_written is None:
+                    prob.set_points(0, init_tri_pts)          # no record of what the device holds: upload everything
+                elif done and not np.array_equal(init_tri_pts[:, :done], scene.pts_written[:, :done]):
                     prob.set_points(0, init_tri_pts[:, :done])
-            prob.iterate(self.damping_factor, self.iteration, self.ba_quirk_flags)
-            cams, pts = prob.get_state()
+            try:
+                prob.iterate(self.damping_factor, self.iteration, self.ba_quirk_flags)
+                cams, pts = prob.get_state()
+            except Exception:
+                # the device state has advanced (or is invalid: a bad rotation) while tri_pts / the views keep the old
+                # values; the reference re-reads them on every call (ba:292-294), so the next call must start from the
+                # host state again: drop the resident copy rather than continue from diverged device points
+                self.ba_release()
+                raise
             scene.pts_written = pts
         else:
             rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]

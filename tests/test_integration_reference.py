@@ -13,19 +13,37 @@ REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists in the build container only")
 
 
+REF_MODULES = ("ba_processor", "campose_processor", "epipolar_processor", "triangulation_processor", "utils",
+               "view_processor", "key_tracker")
+
+
 @pytest.fixture(scope="module")
 def ref():
+    """The reference's modules, imported for this test module only: sys.path, sys.modules (the reference's generically
+    named `utils`, the inert `cv2` placeholder) and sys.dont_write_bytecode are restored on teardown so that no later
+    test of the session picks them up."""
+    saved_path, saved_flag = list(sys.path), sys.dont_write_bytecode
+    saved_mods = {name: sys.modules.get(name) for name in REF_MODULES + ("cv2",)}
     sys.dont_write_bytecode = True                    # the reference directory is read-only
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
-    sys.modules.setdefault("cv2", types.ModuleType("cv2"))      # inert placeholder: OpenCV is absent, the hot path never calls it
+    sys.path.insert(0, REF)
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")  # inert placeholder: OpenCV is absent, the hot path never calls it
+    for name in REF_MODULES:
+        sys.modules.pop(name, None)
     import ba_processor
     import campose_processor
     import epipolar_processor
     import triangulation_processor
     import utils
-    return types.SimpleNamespace(ba=ba_processor, cam=campose_processor, epi=epipolar_processor,
-                                 tri=triangulation_processor, utils=utils)
+    yield types.SimpleNamespace(ba=ba_processor, cam=campose_processor, epi=epipolar_processor,
+                                tri=triangulation_processor, utils=utils)
+    sys.path[:] = saved_path
+    sys.dont_write_bytecode = saved_flag
+    for name, mod in saved_mods.items():
+        if mod is None:
+            sys.modules.pop(name, None)
+        else:
+            sys.modules[name] = mod
 
 
 def _subclasses(sfm, ref):
