@@ -177,6 +177,7 @@ void guard_free(const Block& b) {
 
 hipError_t pool_alloc(void** ptr, size_t bytes) {
   Pool& P = pool();
+  if (bytes > ((size_t)1 << 40)) return hipErrorOutOfMemory;      // a size computed from a negative count: fail, do not loop in round_up_pow2
   if (guard_on()) {
     Block b{};
     const hipError_t e = guard_alloc(ptr, bytes, &b);

@@ -17,9 +17,9 @@ step() {   # step <seconds> <logfile> <cmd...>
 }
 export SFM_TRACE_EXAMPLES="$out/examples.log"
 if [ -n "$kexpr" ]; then
-  step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600 --capture=sys -k "$kexpr"
+  step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 300 --timeout-method=thread --capture=sys -k "$kexpr"
 else
-  step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600 --capture=sys
+  step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 300 --timeout-method=thread --capture=sys
 fi
 tail -5 "$out/pytest_gpu.log"
 step 120 "$out/smoke.log" python __graft_entry__.py smoke

@@ -17,10 +17,10 @@ step() {   # step <seconds> <logfile> <cmd...>
   return 0
 }
 export SFM_TRACE_EXAMPLES="$out/examples.log"
-step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 600 --capture=sys
+step 900 "$out/pytest_gpu.log" python -m pytest tests -m gpu -q -x --timeout 300 --timeout-method=thread --capture=sys
 tail -3 "$out/pytest_gpu.log"
 # the same suite with guard zones around every device buffer (out-of-bounds writes abort with a message)
-SFM_POOL_REDZONE=1 step 900 "$out/pytest_gpu_redzone.log" python -m pytest tests -m gpu -q -x --timeout 600 --capture=sys
+SFM_POOL_REDZONE=1 step 900 "$out/pytest_gpu_redzone.log" python -m pytest tests -m gpu -q -x --timeout 300 --timeout-method=thread --capture=sys
 tail -1 "$out/pytest_gpu_redzone.log"
 step 120 "$out/smoke.log" python __graft_entry__.py smoke
 tail -1 "$out/smoke.log"
