@@ -3,6 +3,7 @@
 //
 //   tri_nonlinear_kernel  <-> TriangulationProcessor.nonlinear_triangulate (triangulation_processor.py:160-234)
 //   pnp_nonlinear_kernel  <-> CamposeProcessor.nonlinear_estimate_cam_pose_pnp (campose_processor.py:308-459)
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -575,9 +576,11 @@ __device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
 // registers across all iterations when the view has at most 256 * PNP_CACHE points; per iteration every thread
 // linearises its points (35 accumulators), a DPP wave reduction + a 35-thread sum over the 4 waves gives the
 // normal equations, one lane solves them and prepares the next camera.
-constexpr int PNP_CACHE = 4;
-
-__global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
+// THREADS = 256 with four cached points per thread serves views of up to 256 points at one point per thread; larger views
+// take THREADS = 512 (eight waves, two cached points per thread up to 1024 points; sixteen waves would cap the kernel at 128 VGPRs and spill): the per-iteration latency of one view
+// is linearisation rounds + a 35-value reduction + a serial 7x7 solve, and only the first shrinks with more lanes.
+template <int THREADS, int PNP_CACHE>
+__global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
                                                             const double* __restrict__ uv_pix,
                                                             const double* __restrict__ X,
                                                             const double* __restrict__ Kmat,
@@ -588,7 +591,8 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
   __shared__ CamPrep cam;
   __shared__ double params[7];
   __shared__ double kinv[9];
-  __shared__ double red[4][35];
+  constexpr int WAVES = THREADS / 64;
+  __shared__ double red[WAVES][35];
   __shared__ double sums[35];
   __shared__ int st_sh;
   const int view = blockIdx.x;
@@ -622,12 +626,12 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
     pt[4] = (kinv[0] * u + kinv[1] * v + kinv[2] * h) / m2;
     pt[5] = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2;
   };
-  const bool cached = n <= 256 * PNP_CACHE;
+  const bool cached = n <= THREADS * PNP_CACHE;
   double pts[PNP_CACHE][6];
   if (cached) {
 #pragma unroll
     for (int c = 0; c < PNP_CACHE; ++c)
-      if (tid + 256 * c < n) load_point(tid + 256 * c, pts[c]);
+      if (tid + THREADS * c < n) load_point(tid + THREADS * c, pts[c]);
   }
 
   for (int it = 0; it < iters && st_sh == SFM_OK; ++it) {
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
     if (cached) {
 #pragma unroll
       for (int cc = 0; cc < PNP_CACHE; ++cc)
-        if (tid + 256 * cc < n) accumulate(pts[cc], tid + 256 * cc);
+        if (tid + THREADS * cc < n) accumulate(pts[cc], tid + THREADS * cc);
     } else {
       for (int p = tid; p < n; p += blockDim.x) {
         double pt[6];
@@ -678,7 +682,12 @@ __global__ __launch_bounds__(256) void pnp_nonlinear_kernel(const int* __restric
       if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
-    if (tid < 35) sums[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 35) {
+      double t = red[0][tid];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) t += red[w][tid];
+      sums[tid] = t;
+    }
     __syncthreads();
     if (tid == 0) {
       double a[28], b[7];
@@ -873,8 +882,10 @@ __global__ void gather_points_kernel(int n, const int* __restrict__ index, const
 
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
-                                 double* R_out, double* C_out, int* status, hipStream_t s) {
-  pnp_nonlinear_kernel<<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
+                                 double* R_out, double* C_out, int* status, hipStream_t s, bool wide) {
+  // `wide`: some view has more than 256 points (the caller knows its offsets; the device-pointer form passes a hint)
+  if (wide) pnp_nonlinear_kernel<512, 2><<<n_views, 512, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
+  else pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
@@ -1082,8 +1093,9 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, co
     set_error("sfm_pnp_nonlinear_batch_dev: null device pointer");
     return SFM_E_SHAPE;
   }
+  // the offsets live on the device: the mean view size decides between the 256- and the 512-thread variant
   SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
-                                d_C_out, d_status, pick_stream(hip_stream)));
+                                d_C_out, d_status, pick_stream(hip_stream), (long long)total > 256LL * n_views));
   return SFM_OK;
 }
 
@@ -1243,8 +1255,10 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   SFM_TRY(dK.upload(K, 9 * (size_t)n_views, s)); SFM_TRY(dR0.upload(R0, 9 * (size_t)n_views, s));
   SFM_TRY(dC0.upload(C0, 3 * (size_t)n_views, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_views)); SFM_TRY(dC.alloc(3 * (size_t)n_views)); SFM_TRY(dSt.alloc(n_views));
+  int widest = 0;
+  for (int v = 0; v < n_views; ++v) widest = std::max(widest, offsets[v + 1] - offsets[v]);
   SFM_TRY(enqueue_pnp_nonlinear(n_views, dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p,
-                                dSt.p, s));
+                                dSt.p, s, widest > 256));
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
   SFM_TRY(stream_sync(s));
