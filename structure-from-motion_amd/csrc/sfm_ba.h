@@ -74,7 +74,7 @@ struct BaDev {
   double* xinv = nullptr;   // [nbk (nbk + 1) / 2 blocks] X = L^-T, block (e, c >= e) at red_blk_base(c, e): the identity carried
                             // through the column steps as extra block rows (sfm_ba_solve.hip); dp = X y is one launch
   int* sync_ctr = nullptr;  // [1] workgroups of ba_inv_apply that have stored their part of dp (self-resetting)
-  int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (bit 32: one-wave elimination)
+  int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (diagnostic stamps, code-path switches)
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
   double* cost = nullptr;   // [kStatSlots] sum |b - f|^2 over this problem's observations at the start of iteration i

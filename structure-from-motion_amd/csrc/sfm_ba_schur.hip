@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0F70
 
 template <bool DIAG, int NS, bool MMA, bool LOADS>
 __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, const double* __restrict__ pb, size_t zp,
-                                             int k_beg, int nslab, int slab_stride, double* __restrict__ img, const int (&oa)[5],
+                                             int k_beg, int nslab, double* __restrict__ img, const int (&oa)[5],
                                              const int (&ob)[5], int wr, int wc, double4_ (&acc)[8]) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: LDS-DMA destinations stay in SGPRs
@@ -95,7 +95,7 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
   // This wave owns rows (wave, wave + 8) of each panel; its global read pointers run along the k dimension.
   const double* ga = pa + (size_t)(k_beg + wave) * zp + 2 * lane;
   const double* gb = pb + (size_t)(k_beg + wave) * zp + 2 * lane;
-  const size_t row8 = 8 * zp, slab_step = (size_t)KSL * zp * slab_stride;
+  const size_t row8 = 8 * zp, slab_step = (size_t)KSL * zp;
   auto dma_piece = [&](int s, int j) {       // piece j of slab s: panel j >> 1, row wave + 8 * (j & 1)
     if (!LOADS) return;
     const double* g = ((j >> 1) ? gb : ga) + (j & 1) * row8;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void schur_k_loop(const double* __restrict__ pa, cons
 
 template <bool DIAG>
 __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, size_t zp, double* __restrict__ slab, int ti,
-                                                int tj, int k_beg, int nslab, int slab_stride, double* __restrict__ img /*[NSTG][2][STAGE]*/,
+                                                int tj, int k_beg, int k_end, double* __restrict__ img /*[NSTG][2][STAGE]*/,
                                                 int ra /*16-row strips of block ti that hold cameras*/, int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -201,9 +201,10 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
 #pragma unroll
   for (int s = 0; s < 5; ++s) { oa[s] = 16 * sx[s]; ob[s] = 16 * sy[s]; }
   const int wr = (wave >> 2) * 64, wc = (wave & 3) * 32;     // off-diagonal tiles: this wave's 64x32 part
+  const int nslab = (k_end - k_beg) / KSL;                   // chunk bounds are multiples of KSL
   // off-diagonal tiles: strips of the row block in this wave's 64-row half
   const int nstrip = __builtin_amdgcn_readfirstlane(max(0, min(4, ra - 4 * (wave >> 2))));
-#define SCHUR_LOOP(D, N, M, L) schur_k_loop<D, N, M, L>(pa, pb, zp, k_beg, nslab, slab_stride, img, oa, ob, wr, wc, acc)
+#define SCHUR_LOOP(D, N, M, L) schur_k_loop<D, N, M, L>(pa, pb, zp, k_beg, nslab, img, oa, ob, wr, wc, acc)
   if (dbg & 5) {      // profiling ablations (1: no MFMA, 4: no staging DMA) on full tiles; results are wrong by design
     const bool mm = !(dbg & 1), ld = !(dbg & 4);
     if (DIAG) {
@@ -262,17 +263,7 @@ struct SchurPlan {
                                 // rows of Zd (dense) or points (sparse) per chunk
   int ra_last;                  // 16-row strips of the last block that hold cameras (1..8)
   int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
-  // XCD-aware split of the dense product (xcd_slots > 0): the hardware deals workgroup b to XCD b % 8, and each XCD has
-  // its own L2.  XCD x owns the contiguous 1/8 of Zd's 16-row slabs [x slabs / 8, (x + 1) slabs / 8); inside it, slot
-  // b / 8 is (tile, phase i of n): the tile's n workgroups on this XCD take the slabs i, i + n, i + 2n, ... of the range.
-  // n is proportional to the tile's MFMAs per k-step, so every workgroup of an XCD sweeps the SAME rows at the SAME rate:
-  // a panel row fetched for one tile is in that XCD's L2 when the other tiles that share the panel ask for it
-  // (each row of Zd crosses the fabric once instead of once per tile that reads it).
-  int xcd_slots;                // workgroups per XCD (0: contiguous chunks, the older split)
-  int slabs;                    // 16-row slabs of Zd
-  unsigned char slot_tile[40], slot_phase[40], slot_n[40];
 };
-constexpr int kXcds = 8;
 
 struct SchurTileRef { int ti, tj, cls, first, chunk; };
 
@@ -449,30 +440,12 @@ __global__ __launch_bounds__(SCHUR_THREADS) void ba_schur_mfma_kernel(BaDev d, d
   extern __shared__ double img[];               // [NSTG stages][A panel, B panel][KSL][ZLD]
   const int w = blockIdx.x;
   double* slab = ws + (size_t)w * (RB * RB);
-  SchurTileRef t;
-  int k_beg, nslab, stride;
-  if (plan.xcd_slots > 0) {
-    const int x = w % kXcds, slot = w / kXcds;
-    const int n = plan.slot_n[slot], i = plan.slot_phase[slot];
-    t = plan_tile(plan, plan.slot_tile[slot]);
-    const int s0 = (int)((long long)plan.slabs * x / kXcds), s1 = (int)((long long)plan.slabs * (x + 1) / kXcds);
-    k_beg = (s0 + i) * KSL;
-    stride = n;
-    nslab = s0 + i < s1 ? (s1 - s0 - i + n - 1) / n : 0;
-    slab = ws + (size_t)(t.first + x * n + i) * (RB * RB);
-  } else {
-    t = plan_locate(plan, w);
-    k_beg = t.chunk * plan.rpc[t.cls];
-    nslab = (min(d.zrows, k_beg + plan.rpc[t.cls]) - k_beg) / KSL;      // chunk bounds are multiples of KSL
-    stride = 1;
-  }
-  if (nslab <= 0) {                          // a scene with fewer slabs than workgroups: this one contributes nothing
-    for (int e = threadIdx.x; e < RB * RB; e += SCHUR_THREADS) slab[e] = 0.0;
-    return;
-  }
+  const SchurTileRef t = plan_locate(plan, w);
+  const int k_beg = t.chunk * plan.rpc[t.cls];
+  const int k_end = min(d.zrows, k_beg + plan.rpc[t.cls]);
   const int ra = (t.cls & 1) ? plan.ra_last : 8;          // strips of the row block that hold cameras
-  if (t.ti != t.tj) schur_tile_body<false>(d.Zd, (size_t)d.zp, slab, t.ti, t.tj, k_beg, nslab, stride, img, ra, plan.dbg);
-  else schur_tile_body<true>(d.Zd, (size_t)d.zp, slab, t.ti, t.ti, k_beg, nslab, stride, img, ra, plan.dbg);
+  if (t.ti != t.tj) schur_tile_body<false>(d.Zd, (size_t)d.zp, slab, t.ti, t.tj, k_beg, k_end, img, ra, plan.dbg);
+  else schur_tile_body<true>(d.Zd, (size_t)d.zp, slab, t.ti, t.ti, k_beg, k_end, img, ra, plan.dbg);
 }
 
 // S(lower) -= sum over the tile's chunk slabs, un-padding block coordinates (block b, row r) -> camera
@@ -568,46 +541,13 @@ static int diag_cost(int ra) {
   return std::max(1, worst);
 }
 
-static SchurPlan make_plan(const BaDev& d, bool xcd_aware = true) {
+static SchurPlan make_plan(const BaDev& d) {
   SchurPlan pl;
   pl.dbg = 0;
-  pl.xcd_slots = 0;
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
   pl.ra_last = (7 * (d.V - (pl.nblk - 1) * CB) + 15) / 16;
   const int slabs = std::max(1, d.zrows / KSL);
-  pl.slabs = slabs;
-  {
-    // XCD-aware split (see SchurPlan): slots per XCD dealt to the tile classes in proportion to their MFMAs per k-step
-    const int slots = std::min(40, ctx().num_cus / kXcds);
-    const int ntiles = pl.n_off + pl.nblk;
-    const double cost[4] = {16.0, 2.0 * pl.ra_last, 9.0, (double)diag_cost(pl.ra_last)};
-    int tiles[4], n[4] = {1, 1, 1, 1};
-    for (int c = 0; c < 4; ++c) tiles[c] = plan_tiles_in_class(pl, c);
-    if (xcd_aware && ctx().num_cus % kXcds == 0 && ntiles <= slots && slabs >= 4 * kXcds * slots) {
-      for (;;) {                                   // one more workgroup per tile for the class with the longest sweep, while slots remain
-        int used = 0, worst = -1;
-        for (int c = 0; c < 4; ++c) used += tiles[c] * n[c];
-        for (int c = 0; c < 4; ++c)
-          if (tiles[c] > 0 && (worst < 0 || cost[c] / n[c] > cost[worst] / n[worst])) worst = c;
-        if (worst < 0 || used + tiles[worst] > slots || n[worst] >= 255) break;
-        ++n[worst];
-      }
-      int slot = 0;
-      for (int tile = 0; tile < ntiles; ++tile) {
-        // class of a tile, without `first` (chunks are not set yet)
-        int cls;
-        if (tile < pl.n_off) cls = tile < tiles[0] ? 0 : 1;
-        else cls = (tile - pl.n_off) < tiles[2] ? 2 : 3;
-        for (int i = 0; i < n[cls]; ++i, ++slot) {
-          pl.slot_tile[slot] = (unsigned char)tile; pl.slot_phase[slot] = (unsigned char)i; pl.slot_n[slot] = (unsigned char)n[cls];
-        }
-      }
-      pl.xcd_slots = slot;
-      for (int c = 0; c < 4; ++c) { pl.chunks[c] = kXcds * n[c]; pl.rpc[c] = 0; }
-      return pl;
-    }
-  }
   // ONE workgroup per CU in total (each needs 144 KB of LDS, so a CU hosts one at a time): a single even
   // round pays the per-workgroup prologue / slab write once.  Rows per chunk are inversely proportional to the
   // class's MFMAs per k-step; shrink the common time budget until everything fits one round.
@@ -654,7 +594,7 @@ int ba_schur_plan(sfm_ba_problem* p) {
   d.zrows = ((3 * d.N + KSL - 1) / KSL) * KSL;
   const SchurPlan pl = make_plan(d);
   const SchurPlan pp = make_pairs_plan(d);
-  const int wgs = std::max(plan_wgs(pl), plan_wgs(make_plan(d, false)));      // either split of the dense product
+  const int wgs = plan_wgs(pl);
   const int wgs_pairs = plan_wgs(pp);
   const size_t ws_dense = sizeof(double) * (size_t)wgs * RB * RB;
   const size_t ws_pairs = sizeof(double) * (size_t)wgs_pairs * RB * RB;
@@ -685,9 +625,13 @@ int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
 }
 
 // Which product kernel the next iteration launches: SFM_SCHUR_MFMA (dense), SFM_SCHUR_ROWS (sparse, row panels) or
-// SFM_SCHUR_PAIRS (sparse, 18-camera tiles).  AUTO compares three cost models fitted on MI355X (profiles/r2n):
-//   dense   ~29 T MAC/s of its (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs + 15 us
-//   tiles   ~0.5 ns per (point, tile) visit + ~0.7 ps per LDS add + 10 us    (C4 share: 975 k visits, 285 M adds -> 0.63 ms)
+// SFM_SCHUR_PAIRS (sparse, 18-camera tiles).  AUTO compares three cost models fitted on MI355X (profiles/r2n for the large
+// scenes; round 3 refitted the constants on 6-30 cameras, profiles/r3/time_small.txt, where round 2's "+15 us" for the dense
+// product made AUTO pick the tiles although the dense kernel was 2-15 us faster from nine cameras on):
+//   dense   ~29 T MAC/s of its (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs + 4 us
+//   tiles   ~0.65 ns per (point, tile) visit + ~0.7 ps per LDS add + the split-K slabs' write and re-read (one used tile per
+//           workgroup at ~8 TB/s) + 4 us   (C4 share: 975 k visits, 285 M adds -> 0.63 ms; 20 x 3000 @ 0.3: 510 workgroups
+//           flushing 126 x 126 tiles -> 22 us against the dense kernel's 6)
 //   rows    ~50 ps per camera pair + ~50 ps per observation + 18 us          (C4 share: 5.8 M pairs -> 0.33 ms; C3: 0.43 ms;
 //           a 6 x 1260 scene: 26 us against the tiles' 17)
 int ba_schur_choice(const sfm_ba_problem* p) {
@@ -701,11 +645,13 @@ int ba_schur_choice(const sfm_ba_problem* p) {
   if (d.N == 0 || d.M == 0) return SFM_SCHUR_PAIRS;
   const double nblk = (double)((d.V + CB - 1) / CB);
   const double kbar = (double)d.M / d.N;
-  const double dense_s = (0.5 * nblk * (nblk - 1) * 64.0 + nblk * 36.0) * 256.0 * 3.0 * d.N / 29e12 + 15e-6;
+  const double dense_s = (0.5 * nblk * (nblk - 1) * 64.0 + nblk * 36.0) * 256.0 * 3.0 * d.N / 29e12 + 4e-6;
   const double nocc = nblk * (1.0 - std::pow(1.0 - 1.0 / nblk, kbar));            // occupied blocks per point
   const double visits = 0.5 * nocc * (nocc + 1.0) * d.N;
   const double pairs = 0.5 * kbar * (kbar + 1) * d.N;
-  const double tiles_s = visits * 0.5e-9 + 49.0 * pairs * 0.7e-12 + 10e-6;
+  const SchurPlan pp = make_pairs_plan(d);
+  const double tile_side = 7.0 * std::min(CB, d.V);
+  const double tiles_s = visits * 0.65e-9 + 49.0 * pairs * 0.7e-12 + plan_wgs(pp) * tile_side * tile_side * 16.0 / 8e12 + 4e-6;
   const double rows_s = rows_possible ? 50e-12 * pairs + 50e-12 * (double)d.M + 18e-6 : 1e30;
   const double mfma_s = p->schur_mfma_ok ? dense_s : 1e30;
   if (mfma_s <= tiles_s && mfma_s <= rows_s) return SFM_SCHUR_MFMA;
@@ -729,7 +675,7 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s) {
     if (!p->rows_ok) choice = SFM_SCHUR_PAIRS;
   }
   if (choice == SFM_SCHUR_MFMA) {
-    pl = make_plan(d, !(p->debug & 1024));      // SFM_OPT_DEBUG bit 1024: the older contiguous-chunk split (same-box A/B)
+    pl = make_plan(d);
     pl.dbg = p->debug;
     const int wgs = plan_wgs(pl);
     ba_tick(p, SFM_K_SCHUR, true, s);

@@ -9,8 +9,7 @@
 //                  row): T = A[r][j] - L[r][j-1] L[j][j-1]^T and D = A[j][j] - L[j][j-1] L[j][j-1]^T on the matrix
 //                  pipe, the operand tiles loaded straight from the k-interleaved blocks into registers (four
 //                  16-byte loads per 16x32 tile, no LDS staging, no barrier before the MFMAs); [D; T] then goes
-//                  through LDS to a four-wave, column-split elimination (chol_trsm_cols; one wave with SFM_OPT_DEBUG
-//                  bit 32) that factors D and solves X L_d^T = T in the same instruction stream (lanes 0-31 = rows
+//                  through LDS to a four-wave, column-split elimination (chol_trsm_cols) that factors D and solves X L_d^T = T in the same instruction stream (lanes 0-31 = rows
 //                  of D, lanes 32-63 = rows of T), two columns per step (2x2 pivots: the two reciprocal square
 //                  roots of a step are independent).  Trailing-role workgroups give the 64x64
 //                  super-tiles right of column j the update of panel j-1, again register-to-register.
@@ -53,54 +52,16 @@ __device__ __forceinline__ void load_operand_rhs(const double* __restrict__ seg,
 }
 
 // ---------------------------------------------------------------------------------------------
-// One wave: a[] = this lane's row (lanes 0..31: rows of the SPD block D, lower part valid; lanes 32..63: rows of
-// T).  On return lanes 0..31 hold the rows of L_d (lower) and lanes 32..63 the rows of X = T L_d^-T.
-//
-// Two columns per step.  With the 2x2 pivot [[a, b], [b, c]] of rows / columns j, j+1:
+// The elimination of one column step, spread over the FOUR waves of the column workgroup (one per SIMD): lanes 0..31 = rows of
+// the SPD block D (lower part valid), lanes 32..63 = rows of T; on return lanes 0..31 hold the rows of L_d and lanes 32..63
+// the rows of X = T L_d^-T.  Two columns per step: with the 2x2 pivot [[a, b], [b, c]] of rows / columns j, j+1,
 //   r1 = 1/sqrt(a), r2 = 1/sqrt(a c - b^2)    -- independent of each other: ONE reciprocal-square-root latency
 //   l11 = a r1, l21 = b r1, 1/l22 = r2 l11    (l22 = sqrt(c - l21^2) = sqrt(det / a))
 //   every row:  x = a_j r1,  y = (a_j+1 - x l21) / l22,   a_k -= x X_k + y Y_k  for k > j+1  (X_k, Y_k = x, y of row k)
-// (sixteen dependent pivot chains per block instead of thirty-two; the cancellation in a c - b^2 is the one
-// c - b^2 / a has).  Software pipeline per step: pivot broadcast (v_readlane) -> chain; the next pair's two columns
-// are updated at once through register broadcasts, all other columns one step later with (X_k, Y_k) read back from
-// LDS as 16-byte wave-uniform (broadcast) reads issued a step ahead.  Single wave => its LDS operations execute in
-// order; no barrier is needed.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chol_trsm_rows(double (&a)[NB], f64x2 (*xy)[64], int lane) {
-  f64x2 prev[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) prev[k] = f64x2{0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < NB / 2; ++s) {
-    const int j = 2 * s;
-    const double pa = lane_bcast(a[j], j), pb = lane_bcast(a[j], j + 1), pc = lane_bcast(a[j + 1], j + 1);
-    const double det = __builtin_fma(pa, pc, -(pb * pb));
-    const double r1 = rsqrt_nr(pa), r2 = rsqrt_nr(det);
-    const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
-    if (s > 0) {                                    // deferred update with pair s-1 (its x, y are a[j-2], a[j-1])
-#pragma unroll
-      for (int k = j + 2; k < NB; ++k) a[k] = __builtin_fma(-a[j - 1], prev[k].y, __builtin_fma(-a[j - 2], prev[k].x, a[k]));
-    }
-    const double x = a[j] * r1;
-    const double y = (a[j + 1] - x * l21) * i22;
-    a[j] = x; a[j + 1] = y;
-    if (j + 2 < NB) {
-      const double x2 = lane_bcast(x, j + 2), y2 = lane_bcast(y, j + 2);
-      const double x3 = lane_bcast(x, j + 3), y3 = lane_bcast(y, j + 3);
-      a[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, a[j + 2]));      // two chained FMAs: one instruction fewer than
-      a[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, a[j + 3]));      // mul + fma + sub on an issue-bound wave
-    }
-    xy[s][lane] = f64x2{x, y};
-#pragma unroll
-    for (int k = j + 4; k < NB; ++k) prev[k] = xy[s][k];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same elimination spread over the FOUR waves of the column workgroup (one per SIMD).  A single wave issues
-// one FP64 instruction every ~7 cycles whatever the dependencies (measured: tools/microbench_solve.hip), so the
-// one-wave version above is bound by its ~85 instructions per pair-step, half of them the update of the far
-// columns.  Here wave w owns columns 8w .. 8w+7 of all 64 rows (lane = row as above, 8 registers).  The pivot chain
+// A single wave issues one FP64 instruction every ~7 cycles whatever the dependencies (tools/microbench_solve.hip), so
+// a one-wave elimination is bound by its ~85 instructions per pair-step, half of them the update of the far columns
+// (rounds 1-2 carried that variant behind a debug switch; its 192 extra VGPRs capped the whole kernel at two waves per
+// SIMD and it is gone).  Here wave w owns columns 8w .. 8w+7 of all 64 rows (lane = row, 8 registers).  The pivot chain
 // walks through the waves: wave `seg` runs the four pair-steps of its columns (pivot broadcast, the two reciprocal
 // square roots, x / y of every row, its own remaining columns) and publishes (x, y) of every row in LDS followed
 // by a step counter; the waves to its right apply each published step to their eight columns as it appears
@@ -167,47 +128,44 @@ __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, i
   const bool fresh = INV && r == j - 1;
   const int lr = lane & 15, lk = lane >> 4;
   double* blk = is_rhs ? nullptr : (INV ? d.xinv + red_blk_base(c, r) : red + red_blk_base(r, c));
-  double old[2][2][4];
-#pragma unroll
-  for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
-        old[sx][sy][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : (fresh ? 0.0 : blk[red_blk_off(i, col)]);
-      }
-  double la[2][8], lb[2][8];
   const double* Lc = red + red_blk_base(c, j - 1);
+  // every global load of the block update is issued before the first MFMA; the two 16-column strips of the block are
+  // finished one after the other so that only half of the accumulators and old values are live at a time (the kernel's
+  // register budget decides how many trailing workgroups a CU holds, and at 200 cameras the trailing traffic, not the
+  // pivot chain, bounds the middle steps)
+  double la[2][8];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     if (is_rhs) load_operand_rhs(rhs + (j - 1) * NB, t, lr, lk, la[t]);
     else load_operand(INV ? d.xinv + red_blk_base(j - 1, r) : red + red_blk_base(r, j - 1), t, lr, lk, la[t]);
-    load_operand(Lc, t, lr, lk, lb[t]);
   }
-  f64x4 acc[2][2];
-#pragma unroll
-  for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-    for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = f64x4{0, 0, 0, 0};
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll 1
+  for (int sy = 0; sy < 2; ++sy) {
+    double lb[8], old[2][4];
+    load_operand(Lc, sy, lr, lk, lb);
 #pragma unroll
     for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-      for (int sy = 0; sy < 2; ++sy) acc[sx][sy] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[sx][ks], lb[sy][ks], acc[sx][sy], 0, 0, 0);
-  }
+      for (int g = 0; g < 4; ++g) {
+        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
+        old[sx][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : (fresh ? 0.0 : blk[red_blk_off(i, col)]);
+      }
+    f64x4 acc[2] = {f64x4{0, 0, 0, 0}, f64x4{0, 0, 0, 0}};
 #pragma unroll
-  for (int sx = 0; sx < 2; ++sx)
+    for (int ks = 0; ks < 8; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0][ks], lb[ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[1][ks], lb[ks], acc[1], 0, 0, 0);
+    }
 #pragma unroll
-    for (int sy = 0; sy < 2; ++sy)
+    for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
-        const double v = old[sx][sy][g] - acc[sx][sy][g];
+        const double v = old[sx][g] - acc[sx][g];
         if (is_rhs) { if (i == 0) rhs[c * NB + col] = v; }
         else blk[red_blk_off(i, col)] = v;
       }
+  }
 }
 
 // Workgroup roles of column step j (with_inv = the identity rows are carried: dp = X y replaces the back substitution):
@@ -321,7 +279,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
   __syncthreads();
   const double(*src)[NB + 1] = lane < NB ? Dm : Tm;
   const int row = lane & (NB - 1);
-  if (!(d.debug & 32)) {
+  {
     // four-wave elimination: this wave's eight columns of all 64 rows
     unsigned long long* stamp3 = (d.stamps && blockIdx.x == 1 && tid == 192) ? d.stamps + 8 * j : nullptr;
     double c[8];
@@ -356,324 +314,6 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
     if (stamp3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp3[5] = __builtin_amdgcn_s_memtime(); }
     return;
   }
-  if (tid >= 64) return;
-  double a[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) a[k] = src[row][k];
-  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
-  chol_trsm_rows(a, xy, lane);
-  if (stamp) { asm volatile("" :: "v"(a[NB - 1])); stamp[4] = __builtin_amdgcn_s_memtime(); }
-  if (r == j) {
-    if (lane >= NB) {
-      // row `row` of X = L_d^-T (upper triangular), stored k-major so that the back substitution's lane i reads
-      // its row with coalesced loads: ldiag[j][k][i] = X[i][k]
-      double* out = d.ldiag + (size_t)j * NB * NB + row;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) { a[k] = (k >= row) ? a[k] : 0.0; out[k * NB] = a[k]; }
-      if (with_inv) {
-        double* out2 = d.xinv + red_blk_base(j, j) + row * 2;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f64x2*>(out2 + m * 256 + q * 64) = f64x2{a[8 * m + q], a[8 * m + q + 4]};
-      }
-    }
-  } else if (lane >= NB) {
-    if (is_rhs) {
-      if (row == 0) {
-#pragma unroll
-        for (int k = 0; k < NB; ++k) rhs[c0 + k] = a[k];
-      }
-    } else {
-      // row `row` of L[r][j] into the k-interleaved block: sixteen (k, k + 4) pairs, each store instruction writing
-      // 32 x 16 contiguous bytes across the lanes
-      double* out = Tblk + row * 2;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f64x2*>(out + m * 256 + q * 64) = f64x2{a[8 * m + q], a[8 * m + q + 4]};
-    }
-  }
-  if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[5] = __builtin_amdgcn_s_memtime(); }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ba_chol_pair: TWO block columns (c0, c1 = c0 + 1) per launch -- the column steps above taken 64 columns at a time on
-// the same packed 32x32 blocks.  Every launch boundary on the critical path of the factorisation costs ~2 us of gap,
-// kernarg and first-load latency plus ~2.5 us of operand fetch / MFMA update / staging before the first pivot, against
-// ~3.4 us for the 32 pivots themselves (profiles/r2/probe_solve.json); with 64 pivots per launch those fixed costs are
-// paid half as often.
-//
-// Column-role workgroup = one 32-row block row (a real row r > c1, the rhs row, or an identity row e <= c1), 16 waves:
-//   prologue   twenty 16x16 tile tasks over the waves: T = [A[r][c0] | A[r][c1]] and D = [[D00, .], [D10, D11]] minus the
-//              update of the PREVIOUS panel (block columns kb_lo .. c0-1: a pair, or the single first column of an odd
-//              nbk) on the matrix pipe, operands register-direct from the k-interleaved L blocks; results to LDS.
-//   elimination  row set A (waves 0-7): lane = row of the 64x64 D, wave = eight columns; the pivot chain walks through
-//              the eight waves exactly as in chol_trsm_cols and publishes (x, y) of every D row plus the pivot scalars per
-//              pair-step.  Row set B (waves 8-15): lanes 0-31 = the 32 rows of T, same column split; wave (B, seg) turns
-//              the published pivots of its segment into (x, y) of the T rows and publishes those, the B waves to its
-//              right fold them in.  B never sits on the chain's critical path; it finishes a step behind it.
-//   stores     B rows -> L[r][c0], L[r][c1] (k-interleaved), X[e][c0], X[e][c1] for identity rows, y for the rhs row.
-//              The factor of D itself is never stored: every workgroup recomputes it, nothing outside the panel reads it.
-// Trailing role: 64x64 super-tiles right of column c1 get the previous panel's update, four super-tiles per workgroup
-// (one per group of four waves), for the real rows and for the identity rows (first touch writes, as above).
-// ---------------------------------------------------------------------------------------------
-constexpr int P2_THREADS = 1024;
-constexpr int P2_LD = 2 * NB + 1;
-struct PairLds {
-  double Dm[2 * NB][P2_LD];
-  double Tm[NB][P2_LD];
-  f64x2 xyA[NB][64];      // [pair-step][row of D] = (x, y)
-  f64x2 xyB[NB][64];      // [pair-step][row of T]
-  f64x4 piv[NB];          // (1 / l11, l21, 1 / l22, -) of the pair-step's 2x2 pivot
-  int flagA, flagB;       // pair-steps published by the chain / by the T rows
-};
-
-__device__ __forceinline__ void pair_elim_A(double (&c)[8], PairLds& L, int lane, int seg_w) {
-#pragma unroll 1
-  for (int seg = 0; seg < 8; ++seg) {
-    if (seg_w == seg) {
-      __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = 2 * t, s = 4 * seg + t, l0 = 8 * seg + j;
-        const double pa = lane_bcast(c[j], l0), pb = lane_bcast(c[j], l0 + 1), pc = lane_bcast(c[j + 1], l0 + 1);
-        const double det = __builtin_fma(pa, pc, -(pb * pb));
-        const double r1 = rsqrt_nr(pa), r2 = rsqrt_nr(det);
-        const double l11 = pa * r1, l21 = pb * r1, i22 = r2 * l11;
-        const double x = c[j] * r1;
-        const double y = (c[j + 1] - x * l21) * i22;
-        c[j] = x; c[j + 1] = y;
-        L.xyA[s][lane] = f64x2{x, y};
-        if (lane == 0) L.piv[s] = f64x4{r1, l21, i22, 0.0};
-        if (t < 3) {
-          const double x2 = lane_bcast(x, l0 + 2), y2 = lane_bcast(y, l0 + 2);
-          const double x3 = lane_bcast(x, l0 + 3), y3 = lane_bcast(y, l0 + 3);
-          c[j + 2] = __builtin_fma(-y, y2, __builtin_fma(-x, x2, c[j + 2]));
-          c[j + 3] = __builtin_fma(-y, y3, __builtin_fma(-x, x3, c[j + 3]));
-#pragma unroll
-          for (int u = j + 4; u < 8; ++u) { const f64x2 q = L.xyA[s][8 * seg + u]; c[u] = __builtin_fma(-y, q.y, __builtin_fma(-x, q.x, c[u])); }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&L.flagA, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      __builtin_amdgcn_s_setprio(0);
-    } else if (seg_w > seg) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int s = 4 * seg + t;
-        while (__hip_atomic_load(&L.flagA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const f64x2 own = L.xyA[s][lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const f64x2 q = L.xyA[s][8 * seg_w + u]; c[u] = __builtin_fma(-own.y, q.y, __builtin_fma(-own.x, q.x, c[u])); }
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void pair_elim_B(double (&c)[8], PairLds& L, int lane, int seg_w) {
-#pragma unroll 1
-  for (int seg = 0; seg < 8; ++seg) {
-    if (seg_w == seg) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = 2 * t, s = 4 * seg + t;
-        while (__hip_atomic_load(&L.flagA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const f64x4 pv = L.piv[s];
-        const double x = c[j] * pv.x;
-        const double y = (c[j + 1] - x * pv.y) * pv.z;
-        c[j] = x; c[j + 1] = y;
-        L.xyB[s][lane] = f64x2{x, y};
-#pragma unroll
-        for (int u = j + 2; u < 8; ++u) { const f64x2 q = L.xyA[s][8 * seg + u]; c[u] = __builtin_fma(-y, q.y, __builtin_fma(-x, q.x, c[u])); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&L.flagB, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    } else if (seg_w > seg) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int s = 4 * seg + t;
-        while (__hip_atomic_load(&L.flagB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const f64x2 own = L.xyB[s][lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const f64x2 q = L.xyA[s][8 * seg_w + u]; c[u] = __builtin_fma(-own.y, q.y, __builtin_fma(-own.x, q.x, c[u])); }
-      }
-    }
-  }
-}
-
-// One wave: block (r, c) right of the panel gets the previous panel's update, A[r][c] -= sum_kb L[r][kb] L[c][kb]^T
-// (INV: E[e][c] -= sum_{kb >= e} X[e][kb] L[c][kb]^T, first touch writes).  Two 16-column strips one after the other
-// (the 1024-thread workgroup leaves 128 VGPRs per lane).
-template <bool INV>
-__device__ __forceinline__ void pair_trailing_block(const BaDev& d, int kb_lo, int c0, int r, int c, int lane) {
-  const int nbk = d.nbk;
-  double* red = d.red;
-  double* rhs = d.red + red_rhs_off(nbk);
-  const bool is_rhs = !INV && r == nbk;
-  const bool fresh = INV && r >= kb_lo;          // no earlier panel has touched this block of the identity rows
-  const int lr = lane & 15, lk = lane >> 4;
-  double* blk = is_rhs ? nullptr : (INV ? d.xinv + red_blk_base(c, r) : red + red_blk_base(r, c));
-#pragma unroll 1
-  for (int sy = 0; sy < 2; ++sy) {
-    f64x4 acc[2] = {f64x4{0, 0, 0, 0}, f64x4{0, 0, 0, 0}};
-    double old[2][4];
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
-        old[sx][g] = is_rhs ? (i == 0 ? rhs[c * NB + col] : 0.0) : (fresh ? 0.0 : blk[red_blk_off(i, col)]);
-      }
-    for (int kb = INV ? max(kb_lo, r) : kb_lo; kb < c0; ++kb) {
-      double la[2][8], lb[8];
-      load_operand(red + red_blk_base(c, kb), sy, lr, lk, lb);
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) {
-        if (is_rhs) load_operand_rhs(rhs + kb * NB, sx, lr, lk, la[sx]);
-        else load_operand(INV ? d.xinv + red_blk_base(kb, r) : red + red_blk_base(r, kb), sx, lr, lk, la[sx]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0][ks], lb[ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[1][ks], lb[ks], acc[1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int i = 16 * sx + lk + 4 * g, col = 16 * sy + lr;
-        const double v = old[sx][g] - acc[sx][g];
-        if (is_rhs) { if (i == 0) rhs[c * NB + col] = v; }
-        else blk[red_blk_off(i, col)] = v;
-      }
-  }
-}
-
-__global__ __launch_bounds__(P2_THREADS) void ba_chol_pair_kernel(BaDev d, int c0, int kb_lo, double lambda) {
-  extern __shared__ __attribute__((aligned(32))) unsigned char pair_lds_raw[];
-  PairLds& L = *reinterpret_cast<PairLds*>(pair_lds_raw);
-  const int P = d.P, nbk = d.nbk;
-  const int c1 = c0 + 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ncol = nbk + 1;                       // real rows c1+1 .. nbk-1, the rhs row, identity rows 0 .. c1
-  const int nreal = nbk - 1 - c1;
-  double* red = d.red;
-  double* rhs = d.red + red_rhs_off(nbk);
-  int role = blockIdx.x;
-  if (role >= ncol) {
-    // ---- trailing roles: four 64x64 super-tiles per workgroup, one per group of four waves ----
-    role -= ncol;
-    const int g4 = wave >> 2, w4 = wave & 3;
-    const int srn = (nbk - c1 + 1) / 2, nst = srn * (srn + 1) / 2;
-    const int nwg_real = (nst + 3) / 4;
-    if (role < nwg_real) {
-      const int tix = 4 * role + g4;
-      if (tix >= nst) return;
-      int t = tix, sr = 0;
-      while (t > sr) { t -= sr + 1; ++sr; }
-      const int r = c1 + 1 + 2 * sr + (w4 >> 1), c = c1 + 1 + 2 * t + (w4 & 1);
-      if (c <= nbk - 1 && r >= c && r <= nbk) pair_trailing_block<false>(d, kb_lo, c0, r, c, lane);
-      return;
-    }
-    role -= nwg_real;
-    const int ncs = (nbk - 1 - c1 + 1) / 2;        // column pairs over c = c1+1 .. nbk-1
-    const int tix = 4 * role + g4;
-    if (ncs <= 0 || tix >= ((c0 + 1) / 2) * ncs) return;
-    const int e = 2 * (tix / ncs) + (w4 >> 1), c = c1 + 1 + 2 * (tix % ncs) + (w4 & 1);
-    if (c <= nbk - 1 && e <= c0 - 1) pair_trailing_block<true>(d, kb_lo, c0, e, c, lane);
-    return;
-  }
-  // ---- column role ----
-  const bool is_rhs = role == nreal;
-  const bool inv_row = role > nreal;
-  const int r = role < nreal ? c1 + 1 + role : nbk;        // block row (real rows / rhs row)
-  const int e = inv_row ? role - nreal - 1 : -1;           // identity row
-  const int lr = lane & 15, lk = lane >> 4;
-  if (tid == 0) { L.flagA = 0; L.flagB = 0; }
-  for (int t = tid; t < NB * NB; t += P2_THREADS) L.Dm[t >> 5][NB + (t & 31)] = 0.0;      // the upper-right block of D is never read for a pivot
-  // twenty tile tasks: block 0, 1 = T against c0, c1; 2 = D00, 3 = D10, 4 = D11; tile q = (sx, sy)
-#pragma unroll 1
-  for (int task = wave; task < 20; task += 16) {
-    const int blk = task >> 2, sx = (task >> 1) & 1, sy = task & 1;
-    const bool isT = blk < 2;
-    const int cc = (blk == 1 || blk == 4) ? c1 : c0;        // block column
-    const int rr = blk == 2 ? c0 : c1;                     // block row of a D block
-    const int ocol = 16 * sy + lr;
-    const bool col_ok = cc * NB + ocol < P;
-    const bool ident = inv_row && e >= c0;                  // identity rows of the panel itself: T = [I | 0] or [0 | I], nothing to update
-    const bool fresh = inv_row && e >= kb_lo;               // first touch of E[e][cc]
-    double old[4];
-    const double* oblk = isT ? (inv_row ? d.xinv + red_blk_base(cc, e) : red + red_blk_base(r, cc)) : red + red_blk_base(rr, cc);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int i = 16 * sx + lk + 4 * g;
-      if (isT) old[g] = is_rhs ? (i == 0 ? rhs[cc * NB + ocol] : 0.0) : (ident ? ((e == cc && i == ocol) ? 1.0 : 0.0) : (fresh ? 0.0 : oblk[red_blk_off(i, ocol)]));
-      else old[g] = oblk[red_blk_off(i, ocol)];
-    }
-    f64x4 acc = {0, 0, 0, 0};
-    if (!(isT && ident)) {
-      for (int kb = (isT && inv_row) ? max(kb_lo, e) : kb_lo; kb < c0; ++kb) {
-        double la[8], lb[8];
-        load_operand(red + red_blk_base(cc, kb), sy, lr, lk, lb);
-        if (!isT) load_operand(red + red_blk_base(rr, kb), sx, lr, lk, la);
-        else if (is_rhs) load_operand_rhs(rhs + kb * NB, sx, lr, lk, la);
-        else load_operand(inv_row ? d.xinv + red_blk_base(kb, e) : red + red_blk_base(r, kb), sx, lr, lk, la);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks], lb[ks], acc, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int i = 16 * sx + lk + 4 * g;
-      const double v = old[g] - acc[g];
-      if (isT) {
-        const bool row_ok = is_rhs ? (i == 0) : (inv_row || r * NB + i < P);
-        L.Tm[i][NB * blk + ocol] = (row_ok && col_ok) ? v : 0.0;
-      } else {
-        double dv = (rr * NB + i < P && col_ok) ? v : 0.0;
-        if (blk != 3 && i == ocol) dv = col_ok ? dv + lambda : 1.0;      // diagonal blocks: + lambda I, identity on padding
-        L.Dm[(blk == 2 ? 0 : NB) + i][(blk == 4 ? NB : 0) + ocol] = dv;
-      }
-    }
-  }
-  __syncthreads();
-  const int seg = wave & 7;
-  double c[8];
-  if (wave < 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = L.Dm[lane][8 * seg + u];
-    pair_elim_A(c, L, lane, seg);
-    return;
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) c[u] = lane < NB ? L.Tm[lane][8 * seg + u] : 0.0;
-  pair_elim_B(c, L, lane, seg);
-  if (lane >= NB) return;
-  const int cc = seg < 4 ? c0 : c1, ws = seg & 3, row = lane;
-  if (is_rhs) {
-    if (row == 0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) rhs[cc * NB + 8 * ws + u] = c[u];
-    }
-    return;
-  }
-  if (inv_row && cc < e) return;      // X[c1][c0] is identically zero, has no slot in the packed buffer and is never read
-  if (inv_row && e == cc) {      // X[e][e] = L_d^-T is upper triangular
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = (8 * ws + u >= row) ? c[u] : 0.0;
-  }
-  // columns 8 ws .. 8 ws + 7 of row `row`: four (k, k + 4) pairs of the k-interleaved block
-  double* out = (inv_row ? d.xinv + red_blk_base(cc, e) : red + red_blk_base(r, cc)) + ws * 256 + row * 2;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<f64x2*>(out + q * 64) = f64x2{c[q], c[q + 4]};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1061,33 +701,6 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   // (tools/time_solve_paths.py) 153 vs 198 us at nbk = 20, 293 vs 340 at 35, 422 vs 448 at 44, 643 vs 640 at 57,
   // 932 vs 910 at 75 -- used up to 52 block columns (V <= 237)
   const bool with_inv = !(d.debug & 512) && nbk <= kInvRowsMaxNbk;
-  if (with_inv && nbk >= 2 && !(d.debug & 2048)) {      // SFM_OPT_DEBUG bit 2048: one block column per launch (same-box A/B)
-    // two block columns per launch; an odd count starts with the single-column step (which has no previous panel)
-    static const bool attr = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PairLds));
-      return true;
-    }();
-    (void)attr;
-    int c0 = 0, kb_lo = 0;
-    if (nbk & 1) {
-      ba_chol_step_kernel<<<nbk + 1, 256, 0, s>>>(d, 0, lambda, 1);
-      c0 = 1;
-    }
-    for (; c0 < nbk; c0 += 2) {
-      const int c1 = c0 + 1;
-      int trail = 0;
-      if (kb_lo < c0) {
-        const int srn = (nbk - c1 + 1) / 2, nst = srn * (srn + 1) / 2;
-        const int ncs = (nbk - 1 - c1 + 1) / 2;
-        trail = (nst + 3) / 4 + (((c0 + 1) / 2) * std::max(0, ncs) + 3) / 4;
-      }
-      ba_chol_pair_kernel<<<nbk + 1 + trail, P2_THREADS, sizeof(PairLds), s>>>(d, c0, kb_lo, lambda);
-      kb_lo = c0;
-    }
-    ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
-    SFM_HIP(hipGetLastError());
-    return SFM_OK;
-  }
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
     // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
