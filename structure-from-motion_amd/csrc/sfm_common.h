@@ -144,6 +144,26 @@ __device__ __forceinline__ void chol3_inv_fast(const double* a, double* li) {
 
 __device__ __forceinline__ double wave_sum(double v) { return group_sum<64>(v); }
 
+// Sum over the wave that is valid in LANE 63 ONLY: the four row sums are folded with the two DPP row broadcasts of the
+// GFX9 family (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of two trips through the LDS
+// crossbar (ds_bpermute) -- for reductions whose result one lane stores anyway.
+__device__ __forceinline__ double dpp_row_bcast_add(double v, bool bcast31) {
+  int lo, hi;
+  if (bcast31) {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x143, 0xC, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x143, 0xC, 0xF, false);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
+  }
+  return v + __hiloint2double(hi, lo);      // disabled rows read 0.0
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v = group_sum<16>(v);
+  v = dpp_row_bcast_add(v, false);
+  return dpp_row_bcast_add(v, true);
+}
+
 // One-sided Jacobi on the columns of B (N x N, row-major B[row][col]): on return the columns of B are
 // mutually orthogonal (B_out = B_in V, column c = sigma_c u_c) and V holds the right singular vectors as
 // columns.  Column order is whatever the sweeps leave; callers pick columns by norm.
@@ -194,6 +214,37 @@ __device__ __forceinline__ double rcp_nr(double d) {
   const double r = __builtin_amdgcn_rcp(d);
   const double e = __builtin_fma(-d, r, 1.0);
   return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+
+// cam_prepare (sfm_math.h) for serial sections of a kernel: the same predicate and the same formulas with the divisions and
+// the square root replaced by v_rcp_f64 / v_rsq_f64 + one third-order step (1e-16 relative; ~10 instructions each instead
+// of ~40).  verify_rotation's one-sided 1e-8 thresholds are ten orders of magnitude above that difference.
+__device__ __forceinline__ int cam_prepare_dev(const double* cam7, CamPrep* out) {
+  out->C[0] = cam7[0]; out->C[1] = cam7[1]; out->C[2] = cam7[2];
+  quat_to_rot(cam7 + 3, out->R);
+  const double* R = out->R;
+  for (int j = 0; j < 3; ++j) out->t[j] = R[0 + j] * -cam7[0] + R[3 + j] * -cam7[1] + R[6 + j] * -cam7[2];
+  const double d = det3(R);
+  bool ok = !(d - 1 >= kRotTol);
+  const double id = rcp_nr(d);
+  const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                         (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                         (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ok = ok && !(inv[3 * i + j] - R[3 * j + i] > kRotTol);
+  if (!ok) return SFM_E_BAD_ROTATION;
+  const double tr1 = 1 + R[0] + R[4] + R[8];
+  if (tr1 < 0) return SFM_E_SQRT_DOMAIN;
+  const double qw = tr1 > 0 ? 0.5 * tr1 * rsqrt_nr(tr1) : 0.0;
+  if (fabs(qw) < kQwMin) return SFM_E_QW_ZERO;
+  const double i4 = rcp_nr(4 * qw);
+  out->q[0] = qw;
+  out->q[1] = (R[7] - R[5]) * i4;
+  out->q[2] = (R[2] - R[6]) * i4;
+  out->q[3] = (R[3] - R[1]) * i4;
+  return SFM_OK;
 }
 
 template <int N>

@@ -172,7 +172,11 @@ void guard_free(const Block& b) {
   (void)hipDeviceSynchronize();
   (void)hipMemUnmap(b.base, b.mapped);
   (void)hipMemRelease(b.handle);
-  (void)hipMemAddressFree(b.base, b.size);
+  // The address range stays RESERVED for the life of the process: hipMemAddressFree followed by a new reservation hands
+  // the same addresses out again, and on this stack (ROCm 7.2, MI355X) the device then kept reading through stale
+  // translations -- 85 of 200 upload / kernel / download round trips came back wrong and BA results varied from run to run
+  // (profiles/r3/guard_mode_diagnostic.txt); with every range used once the same runs are exact.  A never-reused range also
+  // turns a use-after-free into a fault.  The suite reserves a few hundred GB of the 47-bit address space this way.
 }
 }  // namespace
 
@@ -576,25 +580,23 @@ __device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
 // registers across all iterations when the view has at most 256 * PNP_CACHE points; per iteration every thread
 // linearises its points (35 accumulators), a DPP wave reduction + a 35-thread sum over the 4 waves gives the
 // normal equations, one lane solves them and prepares the next camera.
-// THREADS = 256 with four cached points per thread serves views of up to 256 points at one point per thread; larger views
-// take THREADS = 512 (eight waves, two cached points per thread up to 1024 points; sixteen waves would cap the kernel at 128 VGPRs and spill): the per-iteration latency of one view
-// is linearisation rounds + a 35-value reduction + a serial 7x7 solve, and only the first shrinks with more lanes.
+// THREADS = 256 with four cached points per thread serves views of up to 1024 points; larger views take THREADS = 512 (two
+// cached points per thread; sixteen waves would cap the kernel at 128 VGPRs and spill).  More lanes shorten only the
+// linearisation: every wave pays the same 35-value reduction (~630 issue slots) and the same serial 7x7 solve, so at
+// 1000 points 256 threads x 4 points take 4.6 us per iteration against 5.5 us for 512 x 2 (profiles/r3/bench_pnp_*.json).
 template <int THREADS, int PNP_CACHE>
 __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
-                                                            const double* __restrict__ uv_pix,
-                                                            const double* __restrict__ X,
-                                                            const double* __restrict__ Kmat,
-                                                            const double* __restrict__ R0,
-                                                            const double* __restrict__ C0, double lambda, int iters,
-                                                            int quirks, double* __restrict__ R_out,
-                                                            double* __restrict__ C_out, int* __restrict__ status) {
-  __shared__ CamPrep cam;
-  __shared__ double params[7];
-  __shared__ double kinv[9];
+                                                                const double* __restrict__ uv_pix,
+                                                                const double* __restrict__ X,
+                                                                const double* __restrict__ Kmat,
+                                                                const double* __restrict__ R0,
+                                                                const double* __restrict__ C0, double lambda, int iters,
+                                                                int quirks, double* __restrict__ R_out,
+                                                                double* __restrict__ C_out, int* __restrict__ status) {
   constexpr int WAVES = THREADS / 64;
+  __shared__ double kinv[9];
   __shared__ double red[WAVES][35];
   __shared__ double sums[35];
-  __shared__ int st_sh;
   const int view = blockIdx.x;
   const int base = offsets[view];
   const int n = offsets[view + 1] - base;
@@ -608,12 +610,20 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     kinv[0] = (K[4] * K[8] - K[5] * K[7]) * id; kinv[1] = (K[2] * K[7] - K[1] * K[8]) * id; kinv[2] = (K[1] * K[5] - K[2] * K[4]) * id;
     kinv[3] = (K[5] * K[6] - K[3] * K[8]) * id; kinv[4] = (K[0] * K[8] - K[2] * K[6]) * id; kinv[5] = (K[2] * K[3] - K[0] * K[5]) * id;
     kinv[6] = (K[3] * K[7] - K[4] * K[6]) * id; kinv[7] = (K[1] * K[6] - K[0] * K[7]) * id; kinv[8] = (K[0] * K[4] - K[1] * K[3]) * id;
-    // campose:361-371: q0 = q(R0) / |q(R0)|; iteration 0 linearises at (R0, C0) themselves
-    int st = cam_prepare_rc(R0 + 9 * view, C0 + 3 * view, &cam);
-    double nq = sqrt(cam.q[0] * cam.q[0] + cam.q[1] * cam.q[1] + cam.q[2] * cam.q[2] + cam.q[3] * cam.q[3]);
+  }
+  // The serial part of an iteration -- the 7x7 solve, the parameter update, R(q) and its checks -- is carried out by EVERY
+  // thread on the same reduced sums (same instruction stream, same bits): the camera stays in registers, and an iteration
+  // needs two barriers instead of three plus a round trip of the expanded camera through LDS.
+  // campose:361-371: q0 = q(R0) / |q(R0)|; iteration 0 linearises at (R0, C0) themselves
+  CamPrep c;
+  int st = cam_prepare_rc(R0 + 9 * view, C0 + 3 * view, &c);
+  double params[7];
+  {
+    const double inq = rsqrt_nr(c.q[0] * c.q[0] + c.q[1] * c.q[1] + c.q[2] * c.q[2] + c.q[3] * c.q[3]);
+#pragma unroll
     for (int k = 0; k < 3; ++k) params[k] = C0[3 * view + k];
-    for (int k = 0; k < 4; ++k) params[3 + k] = cam.q[k] / nq;
-    st_sh = st;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) params[3 + k] = c.q[k] * inq;
   }
   __syncthreads();
 
@@ -630,15 +640,14 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
   double pts[PNP_CACHE][6];
   if (cached) {
 #pragma unroll
-    for (int c = 0; c < PNP_CACHE; ++c)
-      if (tid + THREADS * c < n) load_point(tid + THREADS * c, pts[c]);
+    for (int cc = 0; cc < PNP_CACHE; ++cc)
+      if (tid + THREADS * cc < n) load_point(tid + THREADS * cc, pts[cc]);
   }
 
-  for (int it = 0; it < iters && st_sh == SFM_OK; ++it) {
+  for (int it = 0; it < iters && st == SFM_OK; ++it) {
     double acc[35];
 #pragma unroll
     for (int k = 0; k < 35; ++k) acc[k] = 0;
-    CamPrep c = cam;                                   // LDS -> registers once per iteration
     auto accumulate = [&](const double (&pt)[6], int p) {
       double pc[3], jp[14];
       project_cam(c, pt[0], pt[1], pt[2], pt[3], pc);
@@ -678,8 +687,8 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     }
 #pragma unroll
     for (int k = 0; k < 35; ++k) {
-      const double s = wave_sum(acc[k]);
-      if (lane == 0) red[wave][k] = s;
+      const double s = wave_sum_lane63(acc[k]);
+      if (lane == 63) red[wave][k] = s;
     }
     __syncthreads();
     if (tid < 35) {
@@ -689,34 +698,28 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
       sums[tid] = t;
     }
     __syncthreads();
-    if (tid == 0) {
-      double a[28], b[7];
+    double a[28], b[7];
 #pragma unroll
-      for (int k = 0; k < 28; ++k) a[k] = sums[k];
+    for (int k = 0; k < 28; ++k) a[k] = sums[k];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        a[i * (i + 1) / 2 + i] += lambda;
-        b[i] = sums[28 + i];
-      }
-      solve7_spd(a, b);
-      for (int i = 0; i < 7; ++i) params[i] += b[i];
-      const double nq = sqrt(params[3] * params[3] + params[4] * params[4] + params[5] * params[5] + params[6] * params[6]);
-      for (int i = 3; i < 7; ++i) params[i] /= nq;
-      // campose:422: R = R(q) validated; the next Jacobian re-derives q from R (campose:464)
-      int st = cam_prepare(params, &cam);
-      if (st != SFM_OK) st_sh = st;
+    for (int i = 0; i < 7; ++i) {
+      a[i * (i + 1) / 2 + i] += lambda;
+      b[i] = sums[28 + i];
     }
-    __syncthreads();
+    solve7_spd(a, b);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) params[i] += b[i];
+    const double inq = rsqrt_nr(params[3] * params[3] + params[4] * params[4] + params[5] * params[5] + params[6] * params[6]);
+#pragma unroll
+    for (int i = 3; i < 7; ++i) params[i] *= inq;
+    // campose:422: R = R(q) validated; the next Jacobian re-derives q from R (campose:464)
+    st = cam_prepare_dev(params, &c);
   }
   if (tid == 0) {
-    if (iters <= 0 && st_sh == SFM_OK) {
-      // no iteration: the reference still returns R(q0) (campose:458)
-      int st = cam_prepare(params, &cam);
-      if (st != SFM_OK) st_sh = st;
-    }
-    for (int k = 0; k < 9; ++k) R_out[9 * view + k] = cam.R[k];
+    if (iters <= 0 && st == SFM_OK) st = cam_prepare_dev(params, &c);      // no iteration: the reference still returns R(q0) (campose:458)
+    for (int k = 0; k < 9; ++k) R_out[9 * view + k] = c.R[k];
     for (int k = 0; k < 3; ++k) C_out[3 * view + k] = params[k];
-    status[view] = st_sh;
+    status[view] = st;
   }
 }
 
@@ -883,7 +886,8 @@ __global__ void gather_points_kernel(int n, const int* __restrict__ index, const
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
                                  double* R_out, double* C_out, int* status, hipStream_t s, bool wide) {
-  // `wide`: some view has more than 256 points (the caller knows its offsets; the device-pointer form passes a hint)
+  // `wide`: some view has more than 1024 points -- more than 256 threads keep in registers (the caller knows its offsets; the
+  // device-pointer form passes a hint)
   if (wide) pnp_nonlinear_kernel<512, 2><<<n_views, 512, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
   else pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
   SFM_HIP(hipGetLastError());
@@ -1093,9 +1097,9 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, co
     set_error("sfm_pnp_nonlinear_batch_dev: null device pointer");
     return SFM_E_SHAPE;
   }
-  // the offsets live on the device: the mean view size decides between the 256- and the 512-thread variant
+  // the offsets live on the device: the mean view size decides between the 256- and the 512-thread variant (> 1024 points)
   SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
-                                d_C_out, d_status, pick_stream(hip_stream), (long long)total > 256LL * n_views));
+                                d_C_out, d_status, pick_stream(hip_stream), (long long)total > 1024LL * n_views));
   return SFM_OK;
 }
 
@@ -1258,7 +1262,7 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   int widest = 0;
   for (int v = 0; v < n_views; ++v) widest = std::max(widest, offsets[v + 1] - offsets[v]);
   SFM_TRY(enqueue_pnp_nonlinear(n_views, dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p,
-                                dSt.p, s, widest > 256));
+                                dSt.p, s, widest > 1024));
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
   SFM_TRY(stream_sync(s));
