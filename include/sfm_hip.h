@@ -263,6 +263,14 @@ int sfm_ba_iterate(sfm_ba_problem* p, double lambda, int iters, int quirks);
 int sfm_ba_get_stats(sfm_ba_problem* p, double* cost /*[max_iters]*/, int max_iters, int* n_iters);
 /* Synchronise, copy the state back, and report the first device-side failure (bad rotation ...). */
 int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts);
+/* sfm_ba_get_state plus R(q) of every camera (what ba_processor.py:412 computes from the refined quaternions with
+ * convert_quaternion_to_rotation, validated: a failing camera is reported exactly as by sfm_ba_get_state). */
+int sfm_ba_get_state_rot(sfm_ba_problem* p, double* cams /*[V][7]*/, double* pts /*[3][N]*/, double* rots /*[V][9]*/);
+/* q <- convert_rotation_to_quaternion(R(q)) for the resident cameras [first, first + count): the round trip through the
+ * rotation matrix that the reference performs between two BA calls (view.rot = R(q) at ba_processor.py:412-413, q = q(view.rot)
+ * at ba:285-288) done on the device, for cameras the caller did not change since the last write-back: the per-view BA call then
+ * uploads nothing for them.  Enqueues only. */
+int sfm_ba_rederive_quaternions(sfm_ba_problem* p, int first, int count);
 /* Grow a resident problem in place — the incremental pipeline registers a view, triangulates new points and
  * re-runs global BA (ba_processor.py:137-267).  n_new_cams cameras (indices V..)
  * and n_new_pts points (indices N..) are appended with their initial state; n_new_obs observations of ANY

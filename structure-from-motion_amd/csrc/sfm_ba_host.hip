@@ -137,6 +137,22 @@ __global__ void ba_append_merge_kernel(int N, int N2, const int* __restrict__ ol
   }
 }
 
+// The reference packs every camera anew at the start of each BA call: q = convert_rotation_to_quaternion(view.rot)
+// (ba_processor.py:285-288), and view.rot is R(q) of the previous call's result (ba:412) -- so the quaternion a call starts
+// from is q(R(q_prev)), not q_prev.  For cameras the caller did not touch, that round trip is done here, on the device, from
+// the R(q) and canonical q the camera expansion holds: nothing crosses PCIe.
+__global__ void ba_rederive_quat_kernel(int first, int count, const CamPrep* __restrict__ prep, double* __restrict__ cams) {
+  const int c = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= first + count) return;
+  for (int k = 0; k < 4; ++k) cams[7 * c + 3 + k] = prep[c].q[k];
+}
+
+__global__ void ba_gather_rot_kernel(int V, const CamPrep* __restrict__ prep, double* __restrict__ rots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * V) return;
+  rots[i] = prep[i / 9].R[i % 9];
+}
+
 static int check_problem(const sfm_ba_problem* p) {
   if (p == nullptr || p->magic != kBaMagic) {
     set_error("invalid bundle-adjustment problem handle");
@@ -470,6 +486,38 @@ int sfm_ba_get_state(sfm_ba_problem* p, double* cams, double* pts) {
     return st[0];
   }
   return SFM_OK;
+}
+
+int sfm_ba_rederive_quaternions(sfm_ba_problem* p, int first, int count) {
+  SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
+  BaDev& d = p->dev;
+  if (first < 0 || count < 0 || first + (long long)count > d.V) {
+    set_error("sfm_ba_rederive_quaternions: range [%d, %d) outside the %d cameras", first, first + count, d.V);
+    return SFM_E_SHAPE;
+  }
+  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));      // R(q) and q(R(q)) of the resident cameras (validated: status)
+  if (count > 0) {
+    ba_rederive_quat_kernel<<<(count + 63) / 64, 64, 0, p->stream>>>(first, count, d.prep[p->cur], d.cams);
+    SFM_HIP(hipGetLastError());
+  }
+  SFM_TRY(ba_reset_stats(p));
+  p->prep_valid = false;          // R(q') differs from R(q) in the last bits: expand again before linearising
+  return SFM_OK;
+}
+
+int sfm_ba_get_state_rot(sfm_ba_problem* p, double* cams, double* pts, double* rots) {
+  SFM_TRY(check_problem(p));
+  if (rots == nullptr) return sfm_ba_get_state(p, cams, pts);
+  SFM_TRY(ba_flush(p));
+  if (!p->prep_valid) SFM_TRY(ba_enqueue_prep(p));
+  BaDev& d = p->dev;
+  DevBuf<double> dR;
+  SFM_TRY(dR.alloc(9 * (size_t)d.V, p->stream));
+  ba_gather_rot_kernel<<<(9 * d.V + 255) / 256, 256, 0, p->stream>>>(d.V, d.prep[p->cur], dR.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dR.download(rots, 9 * (size_t)d.V, p->stream));
+  return sfm_ba_get_state(p, cams, pts);      // synchronises, reports the first device-side failure
 }
 
 int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int n_new_pts, const double* pts_new,

@@ -38,6 +38,7 @@ EXPORTS = (
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
     "sfm_pool_mode", "sfm_tri_nonlinear_dev", "sfm_tri_linear_dev", "sfm_triangulate_dev", "sfm_pnp_nonlinear_batch_dev",
     "sfm_gather_points_dev", "sfm_ba_points_ptr", "sfm_ba_stream", "sfm_ba_event_overhead",
+    "sfm_ba_get_state_rot", "sfm_ba_rederive_quaternions",
 )
 
 _lib = None
@@ -126,6 +127,8 @@ def load():
     lib.sfm_ba_points_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), _ip]
     lib.sfm_ba_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.sfm_ba_event_overhead.argtypes = [vp, ctypes.c_int, _dp]
+    lib.sfm_ba_get_state_rot.argtypes = [vp, _dp, _dp, _dp]
+    lib.sfm_ba_rederive_quaternions.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     _lib = lib
     return lib
 
@@ -501,6 +504,16 @@ class BaProblem:
         cams = np.empty((self.n_cams, 7)); pts = np.empty((3, self.n_pts))
         check(self._lib.sfm_ba_get_state(self._h, dptr(cams), dptr(pts)))
         return cams, pts
+
+    def get_state_rot(self):
+        """(cams (V,7), pts (3,N), rots (V,3,3)): the state plus R(q) of every camera, validated on the device."""
+        cams = np.empty((self.n_cams, 7)); pts = np.empty((3, self.n_pts)); rots = np.empty((self.n_cams, 3, 3))
+        check(self._lib.sfm_ba_get_state_rot(self._h, dptr(cams), dptr(pts), dptr(rots)))
+        return cams, pts, rots
+
+    def rederive_quaternions(self, first, count):
+        """q <- q(R(q)) on the device for cameras [first, first + count) (sfm_ba_rederive_quaternions)."""
+        check(self._lib.sfm_ba_rederive_quaternions(self._h, int(first), int(count)))
 
     def append(self, cams_new, pts_new, obs_cam, obs_pt, uv_norm):
         """Grow the resident scene (sfm_ba_append): new cameras (k,7), new points (3,k), new observations

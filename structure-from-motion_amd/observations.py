@@ -67,3 +67,117 @@ def gather_normalised_keys(views, cam_idx, key_idx):
         pix = np.array([view.key_pts[int(k)].pt for k in key_idx[sel]], dtype=np.float64).reshape(-1, 2).T
         uv[:, sel] = normalise_pixels(pix, view.k)
     return uv
+
+
+class ObservationTracker:
+    """Incremental form of ``build_observations`` for track tables that GROW between two BA calls (the per-view loop of
+    ba_processor.py:137-267: a call registers one more view, new points and new key -> point entries).  ``diff`` looks only
+    at what changed and returns the NEW (cam, pt, key) triples -- exactly the triples by which ``build_observations`` of
+    the new tables exceeds the one of the old tables -- or ``None`` whenever the change is anything but pure growth (an
+    entry that contributed an observation was altered or removed, a second key for a point a view already observes, key
+    index 0: the cases in which quirk Q3's "first key, index 0 does not count" rule could change an EXISTING
+    observation); the caller then rebuilds from scratch with ``reset``."""
+
+    def __init__(self):
+        self.rows = []          # copies of the self rows as of the last reset / diff
+        self.seen = []          # per view: bool (capacity,) -- points the view observes
+        self.n_pts = 0
+
+    def reset(self, self_rows, n_pts):
+        """Full build; returns (pt_ptr, cam_idx, pt_idx, key_idx) of ``build_observations``."""
+        out = build_observations(self_rows, n_pts)
+        _pt_ptr, cam_idx, pt_idx, _key_idx = out
+        self.rows = [np.array(r, copy=True) for r in self_rows]
+        self.n_pts = int(n_pts)
+        self.seen = []
+        for c in range(len(self_rows)):
+            seen = np.zeros(max(n_pts, 1), dtype=bool)
+            seen[pt_idx[cam_idx == c]] = True
+            self.seen.append(seen)
+        return out
+
+    def _grow_seen(self, n_pts):
+        for c, seen in enumerate(self.seen):
+            if seen.shape[0] < n_pts:
+                grown = np.zeros(max(n_pts, 2 * seen.shape[0]), dtype=bool)
+                grown[:seen.shape[0]] = seen
+                self.seen[c] = grown
+
+    def diff(self, self_rows, n_pts):
+        """New triples (cam_idx, pt_idx, key_idx) as int32 arrays (possibly empty), or None -> rebuild."""
+        n_old_views, old_n_pts = len(self.rows), self.n_pts
+        if len(self_rows) < n_old_views or n_pts < old_n_pts:
+            return None
+        cams, pts, keys, changes = [], [], [], []
+        for c in range(n_old_views):
+            row, cached = np.asarray(self_rows[c]), self.rows[c]
+            if row.shape != cached.shape:
+                return None
+            chg = np.flatnonzero(row != cached)
+            if chg.size:
+                was = cached[chg]
+                if np.any((was >= 0) & (was < old_n_pts)):          # an entry that contributed an observation changed
+                    return None
+            cand = chg
+            if n_pts > old_n_pts:                                    # ids that were out of range before and are points now
+                late = np.flatnonzero((cached >= old_n_pts) & (cached < n_pts) & (row == cached))
+                if late.size:
+                    cand = np.union1d(chg, late)
+            if cand.size:
+                ids = row[cand].astype(np.int64, copy=False)
+                ok = (ids >= 0) & (ids < n_pts)
+                cand, ids = cand[ok], ids[ok]
+            if cand.size:
+                if cand[0] == 0:                                     # key index 0 is special (Q3)
+                    return None
+                seen = self.seen[c]
+                old_ids = ids[ids < seen.shape[0]]
+                if np.any(seen[old_ids]) or np.unique(ids).shape[0] != ids.shape[0]:
+                    return None                                      # a second key for an observed point
+                cams.append(np.full(ids.shape[0], c, dtype=np.int64)); pts.append(ids); keys.append(cand.astype(np.int64))
+            changes.append(chg)
+        for c in range(n_old_views, len(self_rows)):
+            t, k = visible_keys(self_rows[c], n_pts)
+            cams.append(np.full(t.shape[0], c, dtype=np.int64)); pts.append(t); keys.append(k)
+        # commit
+        self._grow_seen(n_pts)
+        for c in range(n_old_views):
+            if changes[c].size:
+                self.rows[c][changes[c]] = np.asarray(self_rows[c])[changes[c]]
+        for c in range(n_old_views, len(self_rows)):
+            self.rows.append(np.array(self_rows[c], copy=True))
+            self.seen.append(np.zeros(max(n_pts, 1), dtype=bool))
+        self.n_pts = int(n_pts)
+        if not cams:
+            e = np.empty(0, dtype=np.int32)
+            return e, e.copy(), e.copy()
+        cam_new, pt_new, key_new = np.concatenate(cams), np.concatenate(pts), np.concatenate(keys)
+        for c in np.unique(cam_new):
+            self.seen[int(c)][pt_new[cam_new == c]] = True
+        return cam_new.astype(np.int32), pt_new.astype(np.int32), key_new.astype(np.int32)
+
+
+class KeyCache:
+    """Pixel coordinates of a view's keys as one array (n_keys, 2), converted once per view: ``view.key_pts`` is a list of
+    ``cv2.KeyPoint``-like objects and every BA call gathers the keys of its new observations from it."""
+
+    def __init__(self):
+        self.lists, self.arrays = [], []
+
+    def keys(self, views, c):
+        while len(self.arrays) <= c:
+            self.lists.append(None); self.arrays.append(None)
+        kp = views[c].key_pts
+        if self.lists[c] is not kp or self.arrays[c].shape[0] != len(kp):
+            self.arrays[c] = np.array([k.pt for k in kp], dtype=np.float64).reshape(-1, 2)
+            self.lists[c] = kp
+        return self.arrays[c]
+
+    def gather_normalised(self, views, cam_idx, key_idx):
+        """``gather_normalised_keys`` through the cache."""
+        m = cam_idx.shape[0]
+        uv = np.empty((2, m), dtype=np.float64)
+        for c in np.unique(cam_idx):
+            sel = np.flatnonzero(cam_idx == c)
+            uv[:, sel] = normalise_pixels(self.keys(views, int(c))[key_idx[sel]].T, views[int(c)].k)
+        return uv

@@ -29,7 +29,7 @@ import numpy as np
 
 from . import native
 from .geometry import (pack_cameras, quaternion_to_rotation_unchecked, quaternions_to_rotations)
-from .observations import build_observations, gather_normalised_keys
+from .observations import KeyCache, ObservationTracker, build_observations, gather_normalised_keys
 
 
 # ------------------------------------------------------------------------------------------------
@@ -267,22 +267,22 @@ class HipCamposeProcessor(HipCamposeMixin):
 
 
 # ------------------------------------------------------------------------------------------------
-_CODE_SHIFT = 1 << 20        # observation code = point * 2^20 + view (the reference caps views at filter_size = 10)
-
-
 class _ResidentScene:
-    """What the drop-in keeps between two BA calls of one processor: the device-resident problem and a host
-    picture of what it holds (self-rows of the track tables, observation codes and key indices, intrinsics,
-    the points of the last write-back), enough to decide what is NEW in the next call."""
+    """What the drop-in keeps between two BA calls of one processor: the device-resident problem and a host picture of
+    what it holds (the track-table rows as of the last call, the key coordinates of every view, intrinsics, the poses and
+    points of the last write-back), enough to decide what is NEW in the next call."""
 
     def __init__(self):
         self.prob = None
-        self.rows = []            # copies of track_list[v].table[v, :]
+        self.tracker = ObservationTracker()      # self rows + per-view visibility as of the last call
+        self.keys = KeyCache()                   # (n_keys, 2) pixel coordinates per view, converted once
         self.ks = []              # copies of view.k
+        self.n_views = 0
         self.n_pts = 0
-        self.code = np.empty(0, dtype=np.int64)       # sorted (point, view) codes of the resident observations
-        self.key_idx = np.empty(0, dtype=np.int32)
         self.pts_written = None   # (3, N) the points of the last write-back
+        self.rots_written = None  # (V, 3, 3) / (V, 3): the poses of the last write-back (what view.rot / .loc hold if untouched)
+        self.locs_written = None
+        self.n_views_before = 0
         self.retired_bytes = 0    # upload bytes of problems this scene has replaced
 
     def close(self):
@@ -308,8 +308,9 @@ class HipBaMixin:
     (ba_processor.py:267).  The scene therefore stays resident on the device between calls
     (``ba_resident``): each call diffs the observation list against what the device holds and uploads
     only what is new -- the new view's pose, the new points, the new observations (``sfm_ba_append``) --
-    plus the 7 V camera doubles (the reference re-derives q from R every call, ba:285-288) and whatever
-    old point the caller changed since the last write-back.  If anything was REMOVED (an observation,
+    plus whatever pose or old point the caller changed since the last write-back.  (The reference re-derives every
+    quaternion from ``view.rot`` at the start of a call, ba:285-288; for views whose ``rot`` / ``loc`` still hold what the
+    last call wrote, that round trip q -> R(q) -> q(R) runs on the device, ``sfm_ba_rederive_quaternions``.)  If anything was REMOVED (an observation,
     a point, a view) or an existing key / intrinsic changed, the problem is rebuilt from scratch.
     ``ba_upload_bytes`` reports the PCIe bytes spent so far; ``ba_release()`` frees the device copy."""
 
@@ -329,76 +330,91 @@ class HipBaMixin:
         return scene.upload_bytes if scene is not None else 0
 
     # ---- resident problem ---------------------------------------------------------------------------
-    def _ba_sync_structure(self, views, tri_num, init_cam_poses, init_tri_pts):
-        """Bring the resident problem to the current observation list; returns it."""
+    def _ba_sync_structure(self, views, tri_num, n_same, new_cams, init_tri_pts):
+        """Bring the resident problem to the current observation list; returns it.  ``new_cams`` are the packed cameras of
+        the views from ``n_same`` on (the first ``n_same`` are unchanged since the last write-back).
+
+        The track tables are diffed incrementally (``observations.ObservationTracker``: only the entries that changed
+        since the last call are looked at, ba:309's semantics preserved); pure growth becomes one ``sfm_ba_append``,
+        anything else a rebuild."""
         scene = self.__dict__.get("_hip_scene")
         if scene is None:
             scene = self.__dict__["_hip_scene"] = _ResidentScene()
         view_num = len(views)
+        n_old = scene.n_views_before = scene.n_views
         rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
-        n_old = len(scene.rows)
         same_intrinsics = scene.prob is not None and view_num >= n_old and all(
-            np.array_equal(views[v].k, scene.ks[v]) for v in range(n_old))
-        if (same_intrinsics and view_num == n_old and tri_num == scene.n_pts
-                and all(r.shape == c.shape and np.array_equal(r, c) for r, c in zip(rows, scene.rows))):
-            self.ba_last_action = "reuse"
-            return scene
-        pt_ptr, cam_idx, pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
-        code = pt_idx.astype(np.int64) * _CODE_SHIFT + cam_idx
-        grown = False
-        if same_intrinsics and tri_num >= scene.n_pts and code.shape[0] >= scene.code.shape[0] and view_num < _CODE_SHIFT:
-            pos = np.searchsorted(code, scene.code)
-            inside = pos < code.shape[0]
-            if np.all(inside) and np.array_equal(code[pos], scene.code) and np.array_equal(key_idx[pos], scene.key_idx):
-                fresh = np.ones(code.shape[0], dtype=bool)
-                fresh[pos] = False
-                sel = np.flatnonzero(fresh)
-                uv_new = gather_normalised_keys(views, cam_idx[sel], key_idx[sel])              # ba:339-342, new keys only
-                scene.prob.append(init_cam_poses[n_old:], init_tri_pts[:, scene.n_pts:tri_num], cam_idx[sel], pt_idx[sel], uv_new)
-                grown = True
-                self.ba_last_action = "append"
-        if not grown:
+            views[v].k is scene.ks[v] or np.array_equal(views[v].k, scene.ks[v]) for v in range(n_old))
+        grown = scene.tracker.diff(rows, tri_num) if same_intrinsics else None
+        if grown is not None:
+            cam_new, pt_new, key_new = grown
+            if cam_new.shape[0] == 0 and view_num == n_old and tri_num == scene.n_pts:
+                self.ba_last_action = "reuse"
+                return scene
+            try:
+                uv_new = scene.keys.gather_normalised(views, cam_new, key_new)                  # ba:339-342, new keys only
+                cams_app = new_cams[n_old - n_same:] if n_same <= n_old else pack_cameras(
+                    np.stack([np.asarray(v.rot, dtype=np.float64) for v in views[n_old:]]),
+                    np.stack([np.asarray(v.loc, dtype=np.float64).reshape(3) for v in views[n_old:]]))
+                scene.prob.append(cams_app, init_tri_pts[:, scene.n_pts:tri_num], cam_new, pt_new, uv_new)
+            except Exception:
+                self.ba_release()          # the tracker has moved on, the device has not: start over on the next call
+                raise
+            self.ba_last_action = "append"
+        else:
             scene.close()
-            uv_norm = gather_normalised_keys(views, cam_idx, key_idx)
+            pt_ptr, cam_idx, _pt_idx, key_idx = scene.tracker.reset(rows, tri_num)             # ba:309
+            uv_norm = scene.keys.gather_normalised(views, cam_idx, key_idx)
             scene.prob = native.BaProblem(view_num, pt_ptr, cam_idx, uv_norm)
             scene.pts_written = None
+            scene.rots_written = scene.locs_written = None
             self.ba_last_action = "create"
-        scene.rows = [np.array(r, copy=True) for r in rows]
-        scene.ks = [np.array(v.k, dtype=np.float64, copy=True) for v in views]
+        scene.ks = [v.k for v in views]
+        scene.ks = [np.array(k, dtype=np.float64, copy=True) for k in scene.ks]
+        scene.n_views = view_num
         scene.n_pts = tri_num
-        scene.code, scene.key_idx = code, key_idx
         return scene
-
-    @staticmethod
-    def _ba_host_state(views, tri_pts):
-        cams = pack_cameras(np.stack([np.asarray(v.rot, dtype=np.float64) for v in views]),
-                            np.stack([np.asarray(v.loc, dtype=np.float64).reshape(3) for v in views]))   # ba:285-288
-        return cams, np.ascontiguousarray(tri_pts[0:3, :], dtype=np.float64)                               # ba:292-294
 
     def execute_bundle_adjustment(self):
         views = self.view_processor.view_list
         tri_pts = self.tri_processor.tri_pts
         view_num = len(views)
         tri_num = tri_pts.shape[1]
-        init_cam_poses, init_tri_pts = self._ba_host_state(views, tri_pts)
+        init_rots = np.stack([np.asarray(v.rot, dtype=np.float64) for v in views])                    # ba:287
+        init_locs = np.stack([np.asarray(v.loc, dtype=np.float64).reshape(3) for v in views])         # ba:288
+        init_tri_pts = np.ascontiguousarray(tri_pts[0:3, :], dtype=np.float64)                          # ba:292-294
 
         if self.ba_resident:
-            scene = self._ba_sync_structure(views, tri_num, init_cam_poses, init_tri_pts)
+            scene = self.__dict__.get("_hip_scene")
+            # cameras the caller did not touch since the last write-back: their quaternion q(R(q)) (ba:285-288 after
+            # ba:412) is re-derived on the device; only changed or new views are packed on the host and uploaded
+            n_same = 0
+            if scene is not None and scene.prob is not None and scene.rots_written is not None:
+                n_old = min(scene.rots_written.shape[0], view_num)
+                if np.array_equal(init_rots[:n_old], scene.rots_written[:n_old]) and np.array_equal(init_locs[:n_old], scene.locs_written[:n_old]):
+                    n_same = n_old
+            new_cams = pack_cameras(init_rots[n_same:], init_locs[n_same:]) if n_same < view_num else np.zeros((0, 7))
+            scene = self._ba_sync_structure(views, tri_num, n_same, new_cams, init_tri_pts)
             prob = scene.prob
-            prob.set_cameras(init_cam_poses)
-            done = 0 if scene.pts_written is None else min(scene.pts_written.shape[1], tri_num)
-            if self.ba_last_action == "create":
-                prob.set_points(0, init_tri_pts)
-            else:
-                # points the caller did not touch since the last write-back are already on the device (bit for
-                # bit what get_state returned); appended points went up with sfm_ba_append
-                if scene.pts_written is None:
-                    prob.set_points(0, init_tri_pts)          # no record of what the device holds: upload everything
-                elif done and not np.array_equal(init_tri_pts[:, :done], scene.pts_written[:, :done]):
-                    prob.set_points(0, init_tri_pts[:, :done])
             try:
+                if self.ba_last_action == "create":
+                    prob.set_cameras(pack_cameras(init_rots, init_locs) if n_same else new_cams)
+                    prob.set_points(0, init_tri_pts)
+                else:
+                    if n_same == view_num or (self.ba_last_action == "append" and n_same == scene.n_views_before):
+                        prob.rederive_quaternions(0, n_same)          # appended cameras went up with sfm_ba_append
+                    else:
+                        cams_all = pack_cameras(init_rots, init_locs) if n_same else new_cams
+                        prob.set_cameras(cams_all)
+                    # points the caller did not touch since the last write-back are already on the device (bit for
+                    # bit what get_state returned); appended points went up with sfm_ba_append
+                    done = 0 if scene.pts_written is None else min(scene.pts_written.shape[1], tri_num)
+                    if scene.pts_written is None:
+                        prob.set_points(0, init_tri_pts)          # no record of what the device holds: upload everything
+                    elif done and not np.array_equal(init_tri_pts[:, :done], scene.pts_written[:, :done]):
+                        prob.set_points(0, init_tri_pts[:, :done])
                 prob.iterate(self.damping_factor, self.iteration, self.ba_quirk_flags)
-                cams, pts = prob.get_state()
+                cams, pts, rots = prob.get_state_rot()                                             # ba:412 (validated on the device)
             except Exception:
                 # the device state has advanced (or is invalid: a bad rotation) while tri_pts / the views keep the old
                 # values; the reference re-reads them on every call (ba:292-294), so the next call must start from the
@@ -406,28 +422,29 @@ class HipBaMixin:
                 self.ba_release()
                 raise
             scene.pts_written = pts
+            scene.rots_written, scene.locs_written = rots, cams[:, 0:3].copy()
         else:
+            init_cam_poses = pack_cameras(init_rots, init_locs)
             rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
             pt_ptr, cam_idx, _pt_idx, key_idx = build_observations(rows, tri_num)                  # ba:309
             uv_norm = gather_normalised_keys(views, cam_idx, key_idx)                              # ba:339-342
             cams, pts = native.ba_solve(view_num, pt_ptr, cam_idx, uv_norm, init_cam_poses, init_tri_pts,
                                         self.damping_factor, self.iteration, self.ba_quirk_flags)
+            rots = quaternions_to_rotations(cams[:, 3:7])                                          # ba:412 (validated)
             self.ba_last_action = "solve"
 
-        rots = quaternions_to_rotations(cams[:, 3:7])                                              # ba:412 (validated)
         for view_idx in range(view_num):                                                       # ba:409-413
-            views[view_idx].update_cam_pose(rots[view_idx], cams[view_idx, 0:3].reshape(3, 1).copy())
+            views[view_idx].update_cam_pose(rots[view_idx].copy(), cams[view_idx, 0:3].reshape(3, 1).copy())
         tri_pts[0:3, :] = pts                                                                  # ba:415-416
 
         if self.ba_verbose:                                                                    # ba:418-439
             from scipy.spatial.transform import Rotation
             for view_idx in range(view_num):
-                diff_loc = math.sqrt(np.sum(np.square(init_cam_poses[view_idx, 0:3] - cams[view_idx, 0:3])))
+                diff_loc = math.sqrt(np.sum(np.square(init_locs[view_idx] - cams[view_idx, 0:3])))
                 print('DEBUG: {}-th view loc distance changes {} unit'.format(view_idx, diff_loc))
-                init_rot = quaternion_to_rotation_unchecked(init_cam_poses[view_idx, 3:7])
-                refi_rot = quaternion_to_rotation_unchecked(cams[view_idx, 3:7])
-                init_angle = Rotation.from_matrix(init_rot).as_euler('zyx', degrees=True)
-                refi_angle = Rotation.from_matrix(refi_rot).as_euler('zyx', degrees=True)
+                # (the reference converts its packed quaternions back: R(q(R)) == R to rounding)
+                init_angle = Rotation.from_matrix(init_rots[view_idx]).as_euler('zyx', degrees=True)
+                refi_angle = Rotation.from_matrix(quaternion_to_rotation_unchecked(cams[view_idx, 3:7])).as_euler('zyx', degrees=True)
                 print('DEBUG: {}-th view angles changes {} degree'.format(view_idx, np.abs(init_angle - refi_angle)))
             moved = np.sqrt(np.sum(np.square(init_tri_pts - pts), axis=0))
             for tri_idx in np.flatnonzero(moved >= 5):

@@ -105,3 +105,71 @@ def test_scene_generator_is_seeded_and_well_formed(sfm):
     assert 0.55 < r_true < 0.85                                 # N(0, 0.5 px) per axis -> ~0.707 px
     c3 = sfm.scenes.CONFIGS["C3"]
     assert (c3["n_cams"], c3["n_pts"], c3["visibility"]) == (50, 20000, 0.6)
+
+
+def test_observation_tracker_equals_full_rebuild(sfm):
+    """The incremental observation diff of the drop-in (observations.ObservationTracker) against build_observations on
+    random growing track tables: pure growth must give exactly the missing triples, anything else must ask for a rebuild
+    -- including the Q3 corner cases (key index 0, a second key for an observed point) and ids that become valid only when
+    the point count grows."""
+    obs = sfm.observations
+    rng = np.random.default_rng(11)
+    rebuilds = grows = 0
+    for trial in range(60):
+        n_views, n_keys, n_pts = int(rng.integers(1, 4)), int(rng.integers(4, 40)), int(rng.integers(1, 25))
+        rows = [np.full(n_keys, -1, dtype=np.int64) for _ in range(n_views)]
+        for r in rows:
+            k = rng.choice(np.arange(1, n_keys), size=min(n_keys - 1, int(rng.integers(0, n_keys))), replace=False)
+            r[k] = rng.choice(n_pts + 5, size=k.shape[0], replace=False) if k.shape[0] <= n_pts + 5 else rng.integers(0, n_pts + 5, k.shape[0])
+        tr = obs.ObservationTracker()
+        _ptr, cam, pt, key = tr.reset(rows, n_pts)
+        have = set(zip(cam.tolist(), pt.tolist(), key.tolist()))
+        for step in range(6):
+            kind = rng.integers(0, 6)
+            rows = [r.copy() for r in rows]
+            if kind <= 2:                                   # growth: new points, new entries on free keys, maybe a new view
+                n_pts += int(rng.integers(0, 6))
+                for r in rows:
+                    free = np.flatnonzero(r == -1)
+                    free = free[free > 0]
+                    if free.size:
+                        k = rng.choice(free, size=int(rng.integers(0, min(4, free.size) + 1)), replace=False)
+                        r[k] = rng.integers(0, n_pts + 3, k.shape[0])
+                if kind == 2:
+                    new = np.full(int(rng.integers(3, 30)), -1, dtype=np.int64)
+                    k = rng.choice(new.shape[0], size=int(rng.integers(1, new.shape[0])), replace=False)
+                    new[k] = rng.integers(0, n_pts + 2, k.shape[0])
+                    rows.append(new)
+            elif kind == 3 and rows[0].shape[0] > 1:        # an existing entry is altered
+                rows[0][int(rng.integers(1, rows[0].shape[0]))] = int(rng.integers(-1, n_pts))
+            elif kind == 4:                                 # key index 0 gets an id
+                rows[-1][0] = int(rng.integers(0, n_pts))
+            else:                                           # nothing changes
+                pass
+            want = obs.build_observations(rows, n_pts)
+            want_set = set(zip(want[1].tolist(), want[2].tolist(), want[3].tolist()))
+            got = tr.diff(rows, n_pts)
+            if got is None:
+                rebuilds += 1
+                _ptr, cam, pt, key = tr.reset(rows, n_pts)
+                have = set(zip(cam.tolist(), pt.tolist(), key.tolist()))
+            else:
+                grows += 1
+                new = set(zip(got[0].tolist(), got[1].tolist(), got[2].tolist()))
+                assert len(new) == got[0].shape[0] and not (new & have)
+                have |= new
+            assert have == want_set, (trial, step, kind)
+    assert rebuilds > 10 and grows > 100
+    # the key cache returns what gather_normalised_keys returns
+    class KP:
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class V:
+        pass
+    views = []
+    for c in range(3):
+        v = V(); v.k = sfm.scenes.UPENN_K; v.key_pts = [KP(float(i + c), float(2 * i - c)) for i in range(50)]
+        views.append(v)
+    cam_idx = rng.integers(0, 3, 40).astype(np.int32); key_idx = rng.integers(0, 50, 40).astype(np.int32)
+    assert np.array_equal(obs.KeyCache().gather_normalised(views, cam_idx, key_idx), obs.gather_normalised_keys(views, cam_idx, key_idx))

@@ -235,12 +235,13 @@ def test_incremental_sfm_loop(hip, sfm, oracle):
         tp.tri_pts = full
         # the scene stays resident between the per-view BA calls (ba_processor.py:267): after the first call only
         # what is NEW goes up -- one camera (56 B), 180 points (24 B each), the new observations (24 B each: camera,
-        # point, two doubles) -- plus the 7 V camera doubles the reference re-derives from R on every call
+        # point, two doubles); the old views still hold the poses the last call wrote, so their quaternions are
+        # re-derived from R on the device (the reference does that round trip on the host, ba:285-288)
         actions.append(bp.ba_last_action)
         uploaded.append(bp.ba_upload_bytes)
         if c > 1:
             n_new_obs = (c + 1) * idx.size - c * (idx.size - new.size)
-            assert uploaded[-1] - uploaded[-2] == 56 * 1 + 24 * new.size + 24 * n_new_obs + 56 * (c + 1)
+            assert uploaded[-1] - uploaded[-2] == 56 * 1 + 24 * new.size + 24 * n_new_obs
         nobs = (c + 1) * idx.size
         cam_idx = np.tile(np.arange(c + 1), idx.size).astype(np.int32)
         pt_idx = np.repeat(idx, c + 1).astype(np.int32)
@@ -251,15 +252,32 @@ def test_incremental_sfm_loop(hip, sfm, oracle):
         gcams = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in views])
         assert rel(gcams, ocams) < 1e-9 and rel(tp.tri_pts[0:3, idx], opts[:, idx]) < 1e-9
     assert actions == ["create"] + ["append"] * (n_views - 2)
-    # a further call with nothing new re-uses the resident structure: cameras only (56 V bytes)
+    # a further call with nothing new re-uses the resident structure and uploads NOTHING -- and still equals the oracle
+    # started from the host's view of the state (q re-derived from view.rot, ba:285-288)
+    cams0 = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list])
+    pts0 = tp.tri_pts[0:3].copy()
     before = bp.ba_upload_bytes
     bp._BaProcessor__execute_bundle_adjustment()
-    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 56 * n_views
+    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 0
+    ocams, opts = oracle.ba_sparse(cams0, pts0, cam_idx, pt_idx, uvn, 5, 3)
+    gcams = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list])
+    assert rel(gcams, ocams) < 1e-9 and rel(tp.tri_pts[0:3], opts) < 1e-9
     # ... a caller-side edit of an old point is noticed and uploaded (24 B per resident point), ...
     tp.tri_pts[0, 3] += 1e-3
     before = bp.ba_upload_bytes
     bp._BaProcessor__execute_bundle_adjustment()
-    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 56 * n_views + 24 * n_pts
+    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 24 * n_pts
+    # ... and so is a caller-side change of a pose (all cameras are packed on the host and uploaded: 56 B each)
+    v2 = vp.view_list[2]
+    v2.update_cam_pose(v2.rot.copy(), v2.loc + 1e-4)
+    cams0 = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list])
+    pts0 = tp.tri_pts[0:3].copy()
+    before = bp.ba_upload_bytes
+    bp._BaProcessor__execute_bundle_adjustment()
+    assert bp.ba_last_action == "reuse" and bp.ba_upload_bytes - before == 56 * n_views
+    ocams, opts = oracle.ba_sparse(cams0, pts0, cam_idx, pt_idx, uvn, 5, 3)
+    gcams = np.stack([sfm.geometry.pack_camera(v.rot, v.loc) for v in vp.view_list])
+    assert rel(gcams, ocams) < 1e-9 and rel(tp.tri_pts[0:3], opts) < 1e-9
     # ... and a REMOVED observation forces a rebuild that still matches a from-scratch solve
     kt.track_list[2].table[2, 5] = -1
     snap_views = [(v.rot.copy(), v.loc.copy()) for v in vp.view_list]

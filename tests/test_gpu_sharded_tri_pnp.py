@@ -87,13 +87,22 @@ def test_device_pointer_entry_points_match_host_entry_points(hip, sfm):
     stream.synchronize()
     assert np.array_equal(d_io.cpu().numpy(), hip.tri_nonlinear(projs, uv, x0, 0.5, 30))
     # PnP batch
-    sizes = [300, 1, 1025, 0, 77]
+    sizes = [300, 1, 1000, 0, 77]
     offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=17)
     shard = sfm.sharding.HipPnpShard(offsets, uvp, xs, ks, r0, c0, dev)
     shard.run(5.0, 9)
     rot, loc, st = shard.result()
     rot_h, loc_h, st_h = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 9)
     assert np.array_equal(rot, rot_h) and np.array_equal(loc, loc_h) and np.array_equal(st, st_h)
+    # a view above 1024 points: the host entry point sees the offsets and takes the 512-thread variant, the device-pointer
+    # form decides from the mean view size -- another reduction tree, the same result to rounding
+    sizes = [300, 1500, 40]
+    offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=19)
+    shard = sfm.sharding.HipPnpShard(offsets, uvp, xs, ks, r0, c0, dev)
+    shard.run(5.0, 9)
+    rot, loc, st = shard.result()
+    rot_h, loc_h, st_h = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 9)
+    assert rel(rot, rot_h) < 1e-12 and rel(loc, loc_h) < 1e-12 and np.array_equal(st, st_h)
     tri = sfm.sharding.HipTriShard(projs, uv, x0, dev)
     tri.run(0.5, 30)
     assert np.array_equal(tri.result(), hip.tri_nonlinear(projs, uv, x0, 0.5, 30))

@@ -1,8 +1,10 @@
 #!/bin/bash
 # ONE pass of the GPU suite with SFM_POOL_GUARD=1: every device buffer of the library ends at the end of its own
 # virtual-memory mapping with an unmapped granule behind it, so an out-of-bounds READ faults at the access.
-#   bash tools/gpu_guard.sh <tag>
+#   bash tools/gpu_guard.sh <tag> [pytest targets]
 tag=${1:-guard}
+shift
+targets=${*:-tests}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -22,7 +24,7 @@ PY
 rc=$?; echo "   rc=$rc" | tee -a "$out/steps.log"; cat "$out/probe.log" | grep -v amdgpu.ids
 if [ $rc -ne 0 ]; then echo "guard mode unavailable; stopping" | tee -a "$out/steps.log"; exit 0; fi
 echo "== pytest -m gpu under SFM_POOL_GUARD=1" | tee -a "$out/steps.log"
-SFM_POOL_GUARD=1 timeout -k 10 1000 python -m pytest tests -m gpu -x --timeout 300 --timeout-method=thread --capture=sys -v > "$out/pytest_gpu_guard.log" 2>&1
+SFM_POOL_GUARD=1 timeout -k 10 1000 python -m pytest $targets -m gpu --maxfail=3 --timeout 300 --timeout-method=thread --capture=sys -v > "$out/pytest_gpu_guard.log" 2>&1
 rc=$?; echo "   rc=$rc" | tee -a "$out/steps.log"
 tail -5 "$out/pytest_gpu_guard.log"
 exit 0
