@@ -80,8 +80,6 @@ def steady_state_launches(n_cams, schur_kernel, fused):
     are not among them."""
     p = 7 * n_cams
     nbk = (p + 31) // 32
-    if schur_kernel == "ba_linearize":          # <= 8 cameras: pair products inside the linearisation, single-launch solve
-        return {"ba_linearize": 1, "ba_small_solve": 1}
     launches = {"ba_linearize": 1, schur_kernel: 1, "ba_schur_reduce": 1}
     if schur_kernel == "ba_schur_rows":
         launches["ba_schur_rows_reduce"] = 1
@@ -357,8 +355,8 @@ def run_ba(args, ctx):
         roofline = dict(kernel="ba_" + dominant, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=achieved / HBM_PEAK_GBS)
     # which Schur product the library launched is asked of the library, not guessed from the flags
-    schur_kernel = {native.SCHUR_MFMA: "ba_schur_mfma", native.SCHUR_PAIRS: "ba_schur_pairs", native.SCHUR_ROWS: "ba_schur_rows",
-                    native.SCHUR_INLINE: "ba_linearize"}[engine.prob.info(native.INFO_SCHUR_KERNEL)]
+    schur_kernel = {native.SCHUR_MFMA: "ba_schur_mfma", native.SCHUR_PAIRS: "ba_schur_pairs",
+                    native.SCHUR_ROWS: "ba_schur_rows"}[engine.prob.info(native.INFO_SCHUR_KERNEL)]
     if dominant == "schur":      # the product kernel alone is bracketed (ba_schur_reduce is its own class)
         roofline["kernel"] = schur_kernel
         if schur_kernel != "ba_schur_mfma":      # no MFMA in the sparse products: every product is one ds_add_f64 into an LDS tile / panel

@@ -58,11 +58,9 @@ extern "C" {
 #define SFM_SCHUR_MFMA    2  /* dense v_mfma_f64_16x16x4 SYRK over the materialised, zero-filled Z (LDS-DMA staged; high visibility) */
 #define SFM_SCHUR_ROWS    3  /* sparse product over LDS row panels: one observation owns its camera's block row of its point's
                               * contribution (many cameras at low visibility: BASELINE config 4) */
-#define SFM_SCHUR_INLINE  4  /* reported by SFM_INFO_SCHUR_KERNEL only (not selectable): at most eight cameras with AUTO -- the pair
-                              * products of a point run inside ba_linearize, an iteration is that kernel + ba_small_solve */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 4096 = no in-kernel pair products for <= 8 cameras: results unchanged) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product: results unchanged) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
@@ -76,7 +74,7 @@ extern "C" {
 #define SFM_OPT_TIMING       2  /* bitmask (1 << SFM_K_x): bracket those kernel classes with hipEvents */
 
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
-#define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA / SFM_SCHUR_ROWS / SFM_SCHUR_INLINE: the product kernel the next iteration launches
+#define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA / SFM_SCHUR_ROWS: the product kernel the next iteration launches
                                    * (asking builds the row-panel product's work split if that is the candidate, so the answer is
                                    * the kernel that will run, not the one that was hoped for) */
 #define SFM_INFO_UPLOAD_BYTES  2  /* host -> device bytes moved on behalf of this handle since sfm_ba_create */

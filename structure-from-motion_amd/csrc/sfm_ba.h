@@ -133,7 +133,6 @@ struct sfm_ba_problem {
   int lin_rows = 0;          // rows of lin_ws the last ba_linearize wrote (0: it used global atomics)
   int lin_grid = 0;          // workgroups of the last ba_linearize (rows of cost_ws)
   bool red_clean = false;    // [S | rhs] is known to be all zero (cleared by the last ba_backsub)
-  bool small_pairs_pending = false;   // the last linearisation formed the Schur product itself (<= 8 cameras): ba_small_solve sums its partial costs
   bool backsub_pending = false;   // the reduced solve ran, its back substitution waits for the next launch (ba_flush)
   double pending_lambda = 0;      // ... with these parameters
   int pending_quirks = 0;
@@ -189,7 +188,6 @@ int ba_flush(sfm_ba_problem* p);      // complete a deferred back substitution
 void ba_graph_drop(sfm_ba_problem* p); // forget the captured iteration bodies
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
 bool ba_can_fuse(const sfm_ba_problem* p);
-bool ba_small_pairs(const sfm_ba_problem* p);      // <= 8 cameras, AUTO: pair products inside ba_linearize
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);
 void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out);

@@ -69,17 +69,9 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // ---------------------------------------------------------------------------------------------
 // THREADS = 64 (one wave per workgroup) is the deterministic variant: the camera accumulators in LDS then receive
 // their ds_add_f64 from a single instruction stream, in program order.
-// PAIRS (systems of at most 8 cameras, P <= 56 -- most calls of the reference's incremental loop; G = 8 >= every track):
-// the Schur product of a point is formed RIGHT HERE.  Every lane parks its Z_o (21 doubles + its camera) in LDS; lane a then
-// takes the pairs (a, a + dd mod k), dd = 0 .. k/2 -- each unordered pair of the point's observations once, the same
-// number of partners for every lane -- multiplies Z_a Z_b^T (147 FMA) and subtracts the 7x7 block from a P x P copy of S in
-// LDS (ds_add_f64).  At the end the workgroup folds its camera accumulators into that copy and adds its lower triangle
-// and rhs into [S | rhs] with global f64 atomics (~1 650 per workgroup, a few dozen workgroups).  No Z array, no product
-// launch, no reduce launch: an iteration of a small scene is this kernel + ba_small_solve.
-template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED, int THREADS = 256, bool PAIRS = false>
+template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   static_assert(!FUSED || LDS_MODE == 2, "the fused kernel keeps both camera sets in LDS");
-  static_assert(!PAIRS || (LDS_MODE == 2 && !DENSE_Z && G == 8), "in-kernel pair products: cameras in LDS, eight lanes per point");
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
   int sidx = 0;
@@ -89,8 +81,6 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
   double* lds_acc = lds + (PREP_LDS ? (size_t)d.V * 19 : 0);     // V * 35
   double* lds_old = lds + (size_t)d.V * (19 + 35);               // V * 19 (FUSED): cameras the last step linearised at
   double* lds_delta = lds_old + (size_t)d.V * 19;                // V * 7  (FUSED): their update
-  double* lds_S = lds + (size_t)d.V * (19 + 35 + (FUSED ? 26 : 0));      // P * P (PAIRS): this workgroup's -sum Z Z^T, then + U
-  double* lds_z = lds_S + (size_t)d.P * d.P;                     // THREADS * 22 (PAIRS): Z_o (21) and the camera of every lane
   const CamPrep* gprep = d.prep[cur];
   if (ACC_LDS) {
     if (PREP_LDS) {
@@ -103,12 +93,9 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
       for (int i = threadIdx.x; i < d.V * 7; i += blockDim.x) lds_delta[i] = d.delta[i];
     }
     for (int i = threadIdx.x; i < d.V * 35; i += blockDim.x) lds_acc[i] = 0.0;
-    if (PAIRS) {
-      for (int i = threadIdx.x; i < d.P * d.P; i += blockDim.x) lds_S[i] = 0.0;
-    }
     __syncthreads();
   }
-  if (FUSED && !PAIRS) {      // (PAIRS adds into [S | rhs] from this very launch: ba_small_solve left it cleared)
+  if (FUSED) {
     const size_t n_red = red_size(d.nbk);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_red; i += (size_t)gridDim.x * blockDim.x) d.red[i] = 0.0;
   }
@@ -217,44 +204,7 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
         m1[0] = Jx[3] * li[0];
         m1[1] = Jx[3] * li[1] + Jx[4] * li[2];
         m1[2] = Jx[3] * li[3] + Jx[4] * li[4] + Jx[5] * li[5];
-        if (PAIRS) {
-          double zz[21];
-#pragma unroll
-          for (int i = 0; i < 7; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) zz[3 * i + j] = Jp[i] * m0[j] + Jp[7 + i] * m1[j];
-          }
-          typedef double d2a __attribute__((ext_vector_type(2)));
-          double* zrow = lds_z + (size_t)threadIdx.x * 22;
-#pragma unroll
-          for (int e = 0; e < 20; e += 2) *reinterpret_cast<d2a*>(zrow + e) = d2a{zz[e], zz[e + 1]};
-          *reinterpret_cast<d2a*>(zrow + 20) = d2a{zz[20], (double)cam};
-          // (the wave's LDS operations execute in order: every lane of the group has parked its block before anyone reads)
-          const int k = end - beg;                      // observations of this point = active lanes of the group (k <= G)
-#pragma unroll 1
-          for (int dd = 0; dd <= G / 2; ++dd) {
-            if (!(2 * dd < k || (2 * dd == k && lane_g < dd))) continue;
-            int b = lane_g + dd;
-            if (b >= k) b -= k;
-            const double* zb = lds_z + (size_t)(threadIdx.x - lane_g + b) * 22;
-            double zv[22];
-#pragma unroll
-            for (int e = 0; e < 22; e += 2) { const d2a t = *reinterpret_cast<const d2a*>(zb + e); zv[e] = t.x; zv[e + 1] = t.y; }
-            const int camb = (int)zv[21];
-            const bool ge = lane_g >= b;                // cameras ascend with the lane: mine is the row block, or the partner's
-            const int rbase = 7 * (ge ? cam : camb) * d.P + 7 * (ge ? camb : cam);
-            const int si = ge ? d.P : 1, sj = ge ? 1 : d.P;      // entry (i of mine, j of the partner's) -> row / column stride
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-#pragma unroll
-              for (int j = 0; j < 7; ++j) {
-                if (dd == 0 && j > i) continue;         // a block on the diagonal of S: lower part only
-                const double pr = zz[3 * i] * zv[3 * j] + zz[3 * i + 1] * zv[3 * j + 1] + zz[3 * i + 2] * zv[3 * j + 2];
-                atomicAdd(lds_S + rbase + i * si + j * sj, -pr);
-              }
-            }
-          }
-        } else if (DENSE_Z) {
+        if (DENSE_Z) {
           const int blk = cam / kSchurCB;
           double* zr = d.Zd + (size_t)(3 * p) * d.zp + blk * kSchurRB + 7 * (cam - blk * kSchurCB);
           // 7 consecutive doubles per row, 8-byte aligned: three 16-byte stores + one 8-byte store per row
@@ -322,28 +272,7 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
       d.cost_ws[blockIdx.x] = t;
     }
   }
-  if (PAIRS) {
-    // camera accumulators into the workgroup's copy of S (one owner per entry), then its lower triangle and rhs into
-    // [S | rhs]: a few dozen workgroups x ~1 650 spread atomics (small scenes have few workgroups; at C3 the same flush from
-    // 768 workgroups is what the workspace rows below avoid)
-    __syncthreads();
-    for (int t = threadIdx.x; t < d.V * 35; t += blockDim.x) {
-      const int c = t / 35, e = t - 35 * c;
-      const double v = lds_acc[t];
-      if (e >= 28) { if (v != 0.0) atomicAdd(&rhs[7 * c + (e - 28)], v); }
-      else {
-        int i = 0, base = 0;                   // e = i(i+1)/2 + j
-        while (base + i + 1 <= e) { base += i + 1; ++i; }
-        lds_S[(7 * c + i) * d.P + 7 * c + (e - base)] += v;
-      }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < d.P * d.P; t += blockDim.x) {
-      const int r = t / d.P, c = t - r * d.P;
-      const double v = lds_S[t];
-      if (c <= r && v != 0.0) atomicAdd(&S[red_index(r, c)], v);
-    }
-  } else if (ACC_LDS) {
+  if (ACC_LDS) {
     // per-workgroup partial sums -> workspace row (plain coalesced stores); ba_schur_reduce_kernel adds
     // them into S / rhs.  (Flushing with global atomics made 512 workgroups collide on the same 1750
     // addresses: ~18 G atomics/s on MI355X, 50 us at C3.)
@@ -449,13 +378,6 @@ static int pick_group(const sfm_ba_problem* p) {
   int g = 4;
   while (g < 64 && g < mean) g <<= 1;
   return g;
-}
-
-// Systems of at most eight cameras with AUTO product selection: the pair products run inside ba_linearize (PAIRS).
-bool ba_small_pairs(const sfm_ba_problem* p) {
-  const BaDev& d = p->dev;
-  return d.P <= 56 && d.V <= 8 && p->max_track <= 8 && p->schur_mode == SFM_SCHUR_AUTO && !p->deterministic && !(p->debug & 4096) &&
-         d.N > 0 && d.M > 0;
 }
 
 // `cur` = prep slot of the cameras to linearise at (FUSED: the back substitution uses the other slot)
@@ -569,39 +491,13 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
     if (!p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * red_size(d.nbk), s));
   }
   p->red_clean = false;
-  const bool small = ba_small_pairs(p);
-  const int g = small ? 8 : pick_group(p);
+  const int g = pick_group(p);
   const int gpb = (p->deterministic ? 64 : 256) / g;
   int grid = std::min((d.N + gpb - 1) / gpb, kLinGridPerCu * ctx().num_cus);
   if (grid < 1) grid = 1;
   const size_t lds = sizeof(double) * (size_t)d.V * (19 + 35);
   ba_tick(p, SFM_K_LINEARIZE, true, s);
   p->quirks = quirks;
-  if (small) {
-    // [S | rhs] must be clear before this launch adds into it: ba_small_solve clears what it has read, anything else
-    // (a first call, a forced product kernel before) goes through the memset
-    if (fused && !p->red_clean) SFM_HIP(hipMemsetAsync(d.red, 0, sizeof(double) * red_size(d.nbk), s));
-    const size_t lds_p = sizeof(double) * ((size_t)d.V * (19 + 35 + (fused ? 26 : 0)) + (size_t)d.P * d.P + 256 * 22);
-    static const bool attr = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<8, 2, false, true, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_kernel<8, 2, false, false, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      return true;
-    }();
-    (void)attr;
-    if (fused) {
-      ba_linearize_kernel<8, 2, false, true, 256, true><<<grid, 256, lds_p, s>>>(d, p->cur ^ 1, lambda, quirks);
-      p->backsub_pending = false;
-      p->cur ^= 1;
-    } else {
-      ba_linearize_kernel<8, 2, false, false, 256, true><<<grid, 256, lds_p, s>>>(d, p->cur, lambda, quirks);
-    }
-    p->lin_rows = 0;
-    p->lin_grid = grid;
-    p->small_pairs_pending = true;      // ba_small_solve also sums the partial costs (no reduce launch does it)
-    ba_tick(p, SFM_K_LINEARIZE, false, s);
-    SFM_HIP(hipGetLastError());
-    return SFM_OK;
-  }
   const bool dense_z = ba_schur_uses_mfma(p);
   if (dense_z) SFM_TRY(ba_schur_prepare_dense(p, s));
   if (!dense_z && d.Z == nullptr && d.M > 0) {     // sparse-product path: Z as AoS [M][21] (168 B/obs)

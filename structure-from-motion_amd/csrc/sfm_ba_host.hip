@@ -364,7 +364,7 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
     case SFM_INFO_SCHUR_KERNEL: {
       // the kernel the next iteration WILL launch: the row-panel product needs its camera-major list and work split,
       // which decide whether it can run at all -- build them now rather than answer "rows" and then launch "pairs"
-      int choice = ba_small_pairs(p) ? SFM_SCHUR_INLINE : ba_schur_choice(p);
+      int choice = ba_schur_choice(p);
       if (choice == SFM_SCHUR_ROWS && p->dev.M > 0 && p->dev.N > 0) {
         if (!p->rows_built) {
           SFM_TRY(ba_flush(p));

@@ -544,7 +544,7 @@ constexpr int SM_THREADS = 64 * (SM_COLWAVES + 1), SM_STEPS = 32, SM_LD = 65;
 constexpr int kSmallMaxP = 64;                 // what the kernel can hold
 constexpr int kSmallUseP = 56;                 // what it is used for
 
-__global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int cur, double lambda, int cost_rows) {
+__global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int cur, double lambda) {
   __shared__ f64x2 xy[SM_STEPS][SM_LD];      // [pair-step][row] = (L[row][2s], L[row][2s+1])
   __shared__ f64x4 piv[SM_STEPS];            // (1/l11, l21, 1/l22, -) of the pair's 2x2 pivot
   __shared__ f64x2 ysol[SM_STEPS];           // y = L^-1 rhs, two entries per pair-step
@@ -554,17 +554,9 @@ __global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Pe = (P + 1) & ~1, S = Pe >> 1;  // an odd P gets one identity row / column
   const int nseg = (Pe + SM_SEG - 1) / SM_SEG;
-  double* __restrict__ red = d.red;
-  double* __restrict__ rhs = d.red + red_rhs_off(d.nbk);
+  const double* __restrict__ red = d.red;
+  const double* __restrict__ rhs = d.red + red_rhs_off(d.nbk);
   if (tid == 0) flag = 0;
-  // cost_rows > 0: the linearisation formed the Schur product itself (ba_linearize PAIRS) and no reduce launch has summed its
-  // per-workgroup partial costs: the last column wave (idle up to P = 56) does it here, off the chain's path
-  if (cost_rows > 0 && wave == SM_COLWAVES - 1) {
-    double sum = 0;
-    for (int r = lane; r < cost_rows; r += 64) sum += d.cost_ws[r];
-    sum = wave_sum(sum);
-    if (lane == 0) d.cost[min(*d.iter_count, kStatSlots - 1)] = sum;      // (iter_count advances at the end of this kernel)
-  }
   // diagnostic stamps (SFM_OPT_DEBUG bit 8): [0] start, [1] loaded, [2] factorised, [3] back-substituted, [4] end,
   // [8 + w] wave w takes the chain over
   unsigned long long* stamp = (d.stamps && lane == 0) ? d.stamps : nullptr;
@@ -574,15 +566,12 @@ __global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int
 #pragma unroll
     for (int u = 0; u < SM_SEG; ++u) {
       const int col = SM_SEG * wave + u;
-      const bool have = lane < P && col <= lane;
-      double v = have ? red[red_index(lane, col)] : 0.0;      // lower part; the upper is never used
-      if (have) red[red_index(lane, col)] = 0.0;              // [S | rhs] is read exactly once: leave it cleared for the next linearisation
+      double v = (lane < P && col <= lane) ? red[red_index(lane, col)] : 0.0;      // lower part; the upper is never used
       if (col == lane) v = lane < P ? v + lambda : 1.0;
       c[u] = v;
     }
   } else if (wave == SM_COLWAVES) {
     b = lane < P ? rhs[lane] : 0.0;
-    if (lane < P) rhs[lane] = 0.0;
   }
   // the camera update's operands, long before they are needed
   const int cam_i = SM_THREADS - 1 - tid;
@@ -703,10 +692,8 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   const BaDev& d = p->dev;
   const int nbk = d.nbk;
   if (d.P <= ((d.debug & 256) ? kSmallMaxP : kSmallUseP) && !(d.debug & 64)) {      // SFM_OPT_DEBUG bit 64: block steps for every size; 256: the small kernel up to P = 64
-    ba_small_solve_kernel<<<1, SM_THREADS, 0, s>>>(d, p->cur, lambda, p->small_pairs_pending ? p->lin_grid : 0);
+    ba_small_solve_kernel<<<1, SM_THREADS, 0, s>>>(d, p->cur, lambda);
     SFM_HIP(hipGetLastError());
-    p->small_pairs_pending = false;
-    p->red_clean = true;      // the kernel cleared what it read
     return SFM_OK;
   }
   // the identity rows ride along (SFM_OPT_DEBUG bit 512: leave them out and back-substitute block row by block row).

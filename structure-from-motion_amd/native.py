@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SFM_HIP_LIBRARY") or os.path.join(_HERE, "libsfm_hip.
 OK = 0
 E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK = -1, -2, -3, -4, -5, -6, -7, -8
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
-SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA, SCHUR_ROWS, SCHUR_INLINE = 0, 1, 2, 3, 4
+SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA, SCHUR_ROWS = 0, 1, 2, 3
 OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC, OPT_GRAPH, OPT_TIMING_STRIDE = 1, 2, 3, 4, 5, 6
 K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
