@@ -2,12 +2,12 @@
 # Copy the judged summaries of one tools/gpu_round.sh run (gpurun_out/<tag>/) into profiles/<dest>/ and merge its
 # per-workload HBM traffic into profiles/traffic.json.   bash tools/collect_profiles.sh r2p r2
 src=gpurun_out/${1:?tag}
-dst=profiles/${2:-r2}
+dst=profiles/${2:-r3}
 mkdir -p "$dst"
-for f in trace_iteration_c3.txt trace_iteration_c4share.txt kernel_stats_c3.csv kernel_stats_c4share.csv pmc_sq_summary.csv traffic.json microbench_solve.txt microbench_elim.txt steps.log; do
+for f in trace_iteration_c3.txt trace_iteration_c4share.txt kernel_stats_c3.csv kernel_stats_c4share.csv kernel_stats_tri.csv kernel_stats_pnp.csv pmc_sq_summary.csv traffic.json microbench_solve.txt microbench_elim.txt steps.log; do
   [ -f "$src/$f" ] && cp "$src/$f" "$dst/$f"
 done
-for f in bench bench_c4_share bench_c4_full bench_tri_pnp probe_solve time_schur; do
+for f in bench bench_tri bench_pnp bench_c5 bench_c4_share bench_c4_full bench_tri_pnp probe_solve time_schur; do
   [ -f "$src/$f.log" ] && grep -E '^\{|kernel us|^\[' "$src/$f.log" | tail -20 > "$dst/$f.json"
 done
 for f in time_small stamps_small; do

@@ -3,7 +3,7 @@
 # of box acquisition, so everything rides in one).  Usage (from the repo root on the GPU box):
 #   bash tools/gpu_round.sh [tag]
 # Stops at the first step that is killed / timed out (rc >= 124); ordinary test failures do not stop it.
-tag=${1:-r2}
+tag=${1:-r3}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
@@ -26,6 +26,9 @@ step 120 "$out/smoke.log" python __graft_entry__.py smoke
 tail -1 "$out/smoke.log"
 step 300 "$out/bench.log" python bench.py
 tail -c 400 "$out/bench.log"
+step 240 "$out/bench_tri.log" python bench.py --config TRI --steps 20 --warmup 2
+step 240 "$out/bench_pnp.log" python bench.py --config PNP --steps 20 --warmup 2
+step 300 "$out/bench_c5.log" python bench.py --config C5 --steps 18 --warmup 1
 step 240 "$out/bench_c4_share.log" python bench.py --config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline
 step 240 "$out/bench_c4_full.log" python bench.py --config C4 --steps 5 --warmup 1 --no-cpu-baseline
 step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
@@ -35,6 +38,13 @@ step 120 "$out/time_small.log" python tools/time_small.py
 step 60 "$out/stamps_small.log" python tools/stamps_small.py
 step 60 "$out/microbench_solve.txt" tools/bin/microbench_solve
 step 60 "$out/microbench_elim.txt" tools/bin/microbench_elim
+# kernel durations of the two small solvers (roofline of SURVEY.md section 8(d) item 4)
+for cfg in tri pnp; do
+  up=$(echo $cfg | tr a-z A-Z)
+  step 300 "$out/rocprof_$cfg.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$cfg" -- python3 bench.py --config $up --steps 20 --warmup 2 --no-cpu-baseline
+  f=$(find "$out/prof_$cfg" -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$out/kernel_stats_$cfg.csv" && head -4 "$f"
+done
 for cfg in c3 c4share; do
   if [ $cfg = c3 ]; then args="--no-cpu-baseline"; pargs="--steps 5 --warmup 3 --no-cpu-baseline"; else args="--config C4 --pts 12500 --steps 10 --warmup 2 --no-cpu-baseline"; pargs=$args; fi
   step 300 "$out/rocprof_$cfg.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_$cfg" -- python3 bench.py $args
