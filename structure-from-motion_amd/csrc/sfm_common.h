@@ -144,26 +144,6 @@ __device__ __forceinline__ void chol3_inv_fast(const double* a, double* li) {
 
 __device__ __forceinline__ double wave_sum(double v) { return group_sum<64>(v); }
 
-// Sum over the wave that is valid in LANE 63 ONLY: the four row sums are folded with the two DPP row broadcasts of the
-// GFX9 family (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of two trips through the LDS
-// crossbar (ds_bpermute) -- for reductions whose result one lane stores anyway.
-__device__ __forceinline__ double dpp_row_bcast_add(double v, bool bcast31) {
-  int lo, hi;
-  if (bcast31) {
-    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x143, 0xC, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x143, 0xC, 0xF, false);
-  } else {
-    lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
-  }
-  return v + __hiloint2double(hi, lo);      // disabled rows read 0.0
-}
-__device__ __forceinline__ double wave_sum_lane63(double v) {
-  v = group_sum<16>(v);
-  v = dpp_row_bcast_add(v, false);
-  return dpp_row_bcast_add(v, true);
-}
-
 // One-sided Jacobi on the columns of B (N x N, row-major B[row][col]): on return the columns of B are
 // mutually orthogonal (B_out = B_in V, column c = sigma_c u_c) and V holds the right singular vectors as
 // columns.  Column order is whatever the sweeps leave; callers pick columns by norm.

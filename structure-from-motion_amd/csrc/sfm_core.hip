@@ -595,7 +595,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
                                                                 double* __restrict__ C_out, int* __restrict__ status) {
   constexpr int WAVES = THREADS / 64;
   __shared__ double kinv[9];
-  __shared__ double red[WAVES][35];
+  __shared__ double red[4 * WAVES][35];      // one partial per 16-lane row of every wave
   __shared__ double sums[35];
   const int view = blockIdx.x;
   const int base = offsets[view];
@@ -685,16 +685,19 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
         accumulate(pt, p);
       }
     }
+    // 35 sums over the workgroup: four DPP steps leave the total of every 16-lane row in all of its lanes; the rows'
+    // totals go to LDS (one store instruction per value, four lanes active) and 35 threads add the 4 x WAVES partials --
+    // the two further cross-row steps per value would cost a third of the reduction's ~630 issue slots per wave
 #pragma unroll
     for (int k = 0; k < 35; ++k) {
-      const double s = wave_sum_lane63(acc[k]);
-      if (lane == 63) red[wave][k] = s;
+      const double s = group_sum<16>(acc[k]);
+      if ((lane & 15) == 15) red[4 * wave + (lane >> 4)][k] = s;
     }
     __syncthreads();
     if (tid < 35) {
       double t = red[0][tid];
 #pragma unroll
-      for (int w = 1; w < WAVES; ++w) t += red[w][tid];
+      for (int w = 1; w < 4 * WAVES; ++w) t += red[w][tid];
       sums[tid] = t;
     }
     __syncthreads();
