@@ -53,9 +53,11 @@ EMPTY_KERNEL_MS = 0.0015    # what a kernel that does nothing takes by itself (r
 # (csrc/sfm_core.hip tri_nonlinear_kernel / pnp_nonlinear_kernel; reciprocals counted as 8: seed + third-order step):
 #   triangulation, per view: projection 21 + reciprocal 8 + 1 + Jacobian 24 + residual 4 + J^T J 24 + J^T e 12 = 94;
 #                  per point: damping 3 + adjugate 18 + determinant 5 + reciprocal 8 + update 21 = 55
-#   PnP (quirk Q1: u-rows only): projection 21 + reciprocal 8 + d 3 + J_C 27 + quaternion part 80 + residual 4 + J^T J 56 + J^T e 14 = 213
+#   PnP under the reference's row-stacking quirk Q1 (only the u-row of every point but the last reaches the normal equations,
+#   campose_processor.py:404-405): projection 21 + reciprocal 8 + d 3 + u-row of J_C 12 + its quaternion part 48 + residual 2 +
+#   J^T J 56 + J^T e 14 = 164 (the reference also forms the v-rows it then overwrites: 213 with them)
 TRI_FLOPS_PER_VIEW, TRI_FLOPS_PER_POINT = 94.0, 55.0
-PNP_FLOPS_PER_POINT = 213.0
+PNP_FLOPS_PER_POINT = 164.0
 
 
 def algorithmic_costs(n_cams, pt_ptr, n_obs):

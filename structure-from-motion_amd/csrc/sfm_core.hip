@@ -592,7 +592,12 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
                                                                 const double* __restrict__ R0,
                                                                 const double* __restrict__ C0, double lambda, int iters,
                                                                 int quirks, double* __restrict__ R_out,
-                                                                double* __restrict__ C_out, int* __restrict__ status) {
+                                                                double* __restrict__ C_out, int* __restrict__ status,
+                                                                int stage_mode, int stage_cap) {
+  // Views too large for the register cache keep their points in LDS when they fit (stage_mode 1: X, Y, Z, W and the
+  // normalised key, 48 bytes per point, SoA over stage_cap points; 2: the normalised key only, the point is re-read from
+  // L2): the key normalisation -- two divisions per point -- is then done once, not in every iteration.
+  extern __shared__ double pnp_stage[];
   constexpr int WAVES = THREADS / 64;
   __shared__ double kinv[9];
   __shared__ double red[4 * WAVES][35];      // one partial per 16-lane row of every wave
@@ -637,11 +642,25 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     pt[5] = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2;
   };
   const bool cached = n <= THREADS * PNP_CACHE;
+  const int staged = (!cached && n <= stage_cap) ? stage_mode : 0;
   double pts[PNP_CACHE][6];
   if (cached) {
 #pragma unroll
     for (int cc = 0; cc < PNP_CACHE; ++cc)
       if (tid + THREADS * cc < n) load_point(tid + THREADS * cc, pts[cc]);
+  } else if (staged) {
+    for (int p = tid; p < n; p += THREADS) {
+      double pt[6];
+      load_point(p, pt);
+      if (staged == 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pnp_stage[(size_t)k * stage_cap + p] = pt[k];
+      } else {
+        pnp_stage[p] = pt[4];
+        pnp_stage[(size_t)stage_cap + p] = pt[5];
+      }
+    }
+    __syncthreads();
   }
 
   for (int it = 0; it < iters && st == SFM_OK; ++it) {
@@ -652,9 +671,11 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
       double pc[3], jp[14];
       project_cam(c, pt[0], pt[1], pt[2], pt[3], pc);
       const double iz = rcp_nr(pc[2]);
-      jac_cam_iz(c, pt[0], pt[1], pt[2], pc, iz, quirks, jp);
-      const double eu = pt[4] - pc[0] * iz, ev = pt[5] - pc[1] * iz;
       const bool use_v = !(quirks & SFM_Q1_PNP_ROW_OVERLAP) || (p == n - 1);
+      // quirk Q1 keeps only the u-row of every point but the last: the v-row of the Jacobian is not even formed for them
+      if (use_v) jac_cam_iz(c, pt[0], pt[1], pt[2], pc, iz, quirks, jp);
+      else jac_cam_iz_urow(c, pt[0], pt[1], pt[2], pc, iz, jp);
+      const double eu = pt[4] - pc[0] * iz, ev = pt[5] - pc[1] * iz;
       int k = 0;
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
@@ -681,7 +702,16 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     } else {
       for (int p = tid; p < n; p += blockDim.x) {
         double pt[6];
-        load_point(p, pt);
+        if (staged == 1) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) pt[k] = pnp_stage[(size_t)k * stage_cap + p];
+        } else if (staged == 2) {
+          const size_t col = (size_t)base + p;
+          pt[0] = X[col]; pt[1] = X[(size_t)total + col]; pt[2] = X[2 * (size_t)total + col]; pt[3] = X[3 * (size_t)total + col];
+          pt[4] = pnp_stage[p]; pt[5] = pnp_stage[(size_t)stage_cap + p];
+        } else {
+          load_point(p, pt);
+        }
         accumulate(pt, p);
       }
     }
@@ -888,11 +918,24 @@ __global__ void gather_points_kernel(int n, const int* __restrict__ index, const
 
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
-                                 double* R_out, double* C_out, int* status, hipStream_t s, bool wide) {
-  // `wide`: some view has more than 1024 points -- more than 256 threads keep in registers (the caller knows its offsets; the
-  // device-pointer form passes a hint)
-  if (wide) pnp_nonlinear_kernel<512, 2><<<n_views, 512, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
-  else pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status);
+                                 double* R_out, double* C_out, int* status, hipStream_t s, int widest) {
+  // `widest`: the largest view (the host entry point knows its offsets; the device-pointer form passes twice the mean).  Up to
+  // 1024 points 256 threads keep four points each in registers; beyond that 512 threads work out of LDS: all six values of
+  // a point up to 3 200 points (150 KB), the normalised key alone up to 9 600, nothing beyond (a view above the capacity
+  // of the chosen mode falls back to re-reading inside the kernel).
+  if (widest <= 1024) {
+    pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, 0, 0);
+  } else {
+    static const bool attr = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_nonlinear_kernel<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      return true;
+    }();
+    (void)attr;
+    const int mode = widest <= 3200 ? 1 : (widest <= 9600 ? 2 : 0);
+    const int cap = mode == 1 ? 3200 : (mode == 2 ? 9600 : 0);
+    const size_t lds = sizeof(double) * (size_t)cap * (mode == 1 ? 6 : 2);
+    pnp_nonlinear_kernel<512, 2><<<n_views, 512, lds, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, mode, cap);
+  }
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
@@ -1089,7 +1132,8 @@ int sfm_triangulate_dev(int m, int n_views, const double* d_projs, const double*
 
 int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, const double* d_uv_pix, const double* d_X,
                                 const double* d_K, const double* d_R0, const double* d_C0, double lambda, int iters,
-                                int quirks, double* d_R_out, double* d_C_out, int* d_status, void* hip_stream) {
+                                int quirks, double* d_R_out, double* d_C_out, int* d_status, int max_view_points,
+                                void* hip_stream) {
   SFM_TRY(ensure_init());
   if (n_views < 0 || total < 0 || iters < 0) {
     set_error("sfm_pnp_nonlinear_batch_dev: bad sizes n_views=%d total=%d iters=%d", n_views, total, iters);
@@ -1100,9 +1144,11 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, co
     set_error("sfm_pnp_nonlinear_batch_dev: null device pointer");
     return SFM_E_SHAPE;
   }
-  // the offsets live on the device: the mean view size decides between the 256- and the 512-thread variant (> 1024 points)
+  // the offsets live on the device: the caller says how large its largest view is (0: unknown -- the mean stands in; a
+  // view above what the chosen variant keeps on chip is still correct, it re-reads its points every iteration)
+  const int widest = max_view_points > 0 ? max_view_points : (int)((long long)total / n_views);
   SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
-                                d_C_out, d_status, pick_stream(hip_stream), (long long)total > 1024LL * n_views));
+                                d_C_out, d_status, pick_stream(hip_stream), widest));
   return SFM_OK;
 }
 
@@ -1265,7 +1311,7 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   int widest = 0;
   for (int v = 0; v < n_views; ++v) widest = std::max(widest, offsets[v + 1] - offsets[v]);
   SFM_TRY(enqueue_pnp_nonlinear(n_views, dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p,
-                                dSt.p, s, widest > 1024));
+                                dSt.p, s, widest));
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
   SFM_TRY(stream_sync(s));

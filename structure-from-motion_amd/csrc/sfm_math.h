@@ -143,6 +143,24 @@ SFM_HD void jac_cam_iz(const CamPrep& c, double X, double Y, double Z, const dou
   }
 }
 
+// The u-row of Jp alone (Jp[0..6]): all that the reference's PnP keeps of every point but the last one under its row-stacking
+// quirk Q1 (campose_processor.py:404-405) -- the B sums and the seven v-row entries are not formed.
+SFM_HD void jac_cam_iz_urow(const CamPrep& c, double X, double Y, double Z, const double* p, double iz, double* Jp) {
+  const double* R = c.R;
+  const double px = p[0], pz = p[2];
+  const double iz2 = iz * iz;
+  const double d0 = X - c.C[0], d1 = Y - c.C[1], d2 = Z - c.C[2];
+  for (int i = 0; i < 3; ++i) Jp[i] = (px * R[3 * i + 2] - pz * R[3 * i + 0]) * iz2;
+  const double w2 = 2 * c.q[0], x2 = 2 * c.q[1], y2 = 2 * c.q[2], z2 = 2 * c.q[3];
+  const double x4 = 4 * c.q[1], y4 = 4 * c.q[2], z4 = 4 * c.q[3];
+  double A[4], C[4];
+  A[0] = d1 * z2 - d2 * y2;            C[0] = d0 * y2 - d1 * x2;
+  A[1] = d1 * y2 + d2 * z2;            C[1] = d0 * z2 - d1 * w2 - d2 * x4;
+  A[2] = d1 * x2 - d0 * y4 - d2 * w2;  C[2] = d0 * w2 + d1 * z2 - d2 * y4;
+  A[3] = d1 * w2 - d0 * z4 + d2 * x2;  C[3] = d0 * x2 + d1 * y2;
+  for (int k = 0; k < 4; ++k) Jp[3 + k] = (pz * A[k] - px * C[k]) * iz2;
+}
+
 SFM_HD void jac_cam(const CamPrep& c, double X, double Y, double Z, const double* p, int quirks,
                     double* Jp) {
   jac_cam_iz(c, X, Y, Z, p, 1.0 / p[2], quirks, Jp);

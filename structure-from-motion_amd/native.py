@@ -122,7 +122,7 @@ def load():
     lib.sfm_tri_linear_dev.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
     lib.sfm_triangulate_dev.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp]
     lib.sfm_pnp_nonlinear_batch_dev.argtypes = [ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_int,
-                                                ctypes.c_int, vp, vp, vp, vp]
+                                                ctypes.c_int, vp, vp, vp, ctypes.c_int, vp]
     lib.sfm_gather_points_dev.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp]
     lib.sfm_ba_points_ptr.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), _ip]
     lib.sfm_ba_stream.argtypes = [vp, ctypes.POINTER(vp)]
@@ -215,10 +215,10 @@ def triangulate_dev(m, n_views, d_projs, d_uv, lam, iters, d_x_out, stream=0):
 
 
 def pnp_nonlinear_batch_dev(n_views, d_offsets, total, d_uv_pix, d_x, d_k, d_r0, d_c0, lam, iters, quirks, d_r_out, d_c_out,
-                            d_status, stream=0):
+                            d_status, stream=0, max_view_points=0):
     check(load().sfm_pnp_nonlinear_batch_dev(int(n_views), _vp(d_offsets), int(total), _vp(d_uv_pix), _vp(d_x), _vp(d_k), _vp(d_r0),
                                              _vp(d_c0), float(lam), int(iters), int(quirks), _vp(d_r_out), _vp(d_c_out),
-                                             _vp(d_status), _vp(stream)))
+                                             _vp(d_status), int(max_view_points), _vp(stream)))
 
 
 def gather_points_dev(n, d_index, d_px, d_py, d_pz, d_x_out, stream=0):

@@ -344,7 +344,7 @@ class HipBaMixin:
         n_old = scene.n_views_before = scene.n_views
         rows = [self.key_tracker.track_list[v].table[v, :] for v in range(view_num)]
         same_intrinsics = scene.prob is not None and view_num >= n_old and all(
-            views[v].k is scene.ks[v] or np.array_equal(views[v].k, scene.ks[v]) for v in range(n_old))
+            np.array_equal(views[v].k, scene.ks[v]) for v in range(n_old))
         grown = scene.tracker.diff(rows, tri_num) if same_intrinsics else None
         if grown is not None:
             cam_new, pt_new, key_new = grown
@@ -369,8 +369,7 @@ class HipBaMixin:
             scene.pts_written = None
             scene.rots_written = scene.locs_written = None
             self.ba_last_action = "create"
-        scene.ks = [v.k for v in views]
-        scene.ks = [np.array(k, dtype=np.float64, copy=True) for k in scene.ks]
+        scene.ks = [np.array(v.k, dtype=np.float64, copy=True) for v in views]
         scene.n_views = view_num
         scene.n_pts = tri_num
         return scene

@@ -327,6 +327,7 @@ class HipPnpShard:
         native.init(self.device.index or 0)
         self.stream = torch.cuda.Stream(self.device)
         self.n_views, self.total = int(np.asarray(offsets_local).shape[0]) - 1, int(np.asarray(uv_local).shape[1])
+        self.widest = int(np.max(np.diff(np.asarray(offsets_local)))) if self.n_views > 0 else 0
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)      # noqa: E731
         with torch.cuda.stream(self.stream):
             self.offsets = up(offsets_local, np.int32)
@@ -340,7 +341,8 @@ class HipPnpShard:
     def run(self, lam, iters, quirks=native.QUIRKS_REFERENCE):
         native.pnp_nonlinear_batch_dev(self.n_views, self.offsets.data_ptr(), self.total, self.uv.data_ptr(), self.x.data_ptr(),
                                        self.k.data_ptr(), self.r0.data_ptr(), self.c0.data_ptr(), lam, iters, quirks,
-                                       self.r_out.data_ptr(), self.c_out.data_ptr(), self.status.data_ptr(), self.stream.cuda_stream)
+                                       self.r_out.data_ptr(), self.c_out.data_ptr(), self.status.data_ptr(), self.stream.cuda_stream,
+                                       self.widest)
 
     def result(self):
         self.stream.synchronize()

@@ -94,15 +94,24 @@ def test_device_pointer_entry_points_match_host_entry_points(hip, sfm):
     rot, loc, st = shard.result()
     rot_h, loc_h, st_h = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 9)
     assert np.array_equal(rot, rot_h) and np.array_equal(loc, loc_h) and np.array_equal(st, st_h)
-    # a view above 1024 points: the host entry point sees the offsets and takes the 512-thread variant, the device-pointer
-    # form decides from the mean view size -- another reduction tree, the same result to rounding
-    sizes = [300, 1500, 40]
-    offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=19)
-    shard = sfm.sharding.HipPnpShard(offsets, uvp, xs, ks, r0, c0, dev)
-    shard.run(5.0, 9)
-    rot, loc, st = shard.result()
-    rot_h, loc_h, st_h = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 9)
-    assert rel(rot, rot_h) < 1e-12 and rel(loc, loc_h) < 1e-12 and np.array_equal(st, st_h)
+    # views above 1024 points work out of LDS (all of a point up to 3 200 points, the normalised key alone up to 9 600,
+    # re-reading beyond): the same variant through both entry points when the device-pointer form is told the largest view
+    for sizes in ([300, 1500, 40], [3300, 10, 1025], [9700, 600]):
+        offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=19)
+        shard = sfm.sharding.HipPnpShard(offsets, uvp, xs, ks, r0, c0, dev)
+        shard.run(5.0, 6)
+        rot, loc, st = shard.result()
+        rot_h, loc_h, st_h = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 6)
+        assert np.array_equal(rot, rot_h) and np.array_equal(loc, loc_h) and np.array_equal(st, st_h)
+    # ... and without the hint (the mean stands in: 256 threads re-reading the big view) the same result to rounding
+    d = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)      # noqa: E731
+    t_off, t_uv, t_x, t_k, t_r0, t_c0 = d(offsets, np.int32), d(uvp), d(xs), d(ks.reshape(-1, 9)), d(r0.reshape(-1, 9)), d(c0)
+    t_r, t_c, t_st = torch.empty_like(t_r0), torch.empty_like(t_c0), torch.zeros(len(sizes), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hip.pnp_nonlinear_batch_dev(len(sizes), t_off.data_ptr(), uvp.shape[1], t_uv.data_ptr(), t_x.data_ptr(), t_k.data_ptr(), t_r0.data_ptr(),
+                                t_c0.data_ptr(), 5.0, 6, hip.QUIRKS_REFERENCE, t_r.data_ptr(), t_c.data_ptr(), t_st.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert rel(t_r.cpu().numpy().reshape(-1, 3, 3), rot_h) < 1e-12 and rel(t_c.cpu().numpy(), loc_h) < 1e-12
     tri = sfm.sharding.HipTriShard(projs, uv, x0, dev)
     tri.run(0.5, 30)
     assert np.array_equal(tri.result(), hip.tri_nonlinear(projs, uv, x0, 0.5, 30))
@@ -136,7 +145,8 @@ def test_pnp_on_resident_ba_points(hip, sfm):
         torch.cuda.synchronize()
         hip.gather_points_dev(idx.shape[0], d_idx.data_ptr(), px, py, pz, d_x.data_ptr(), stream)
         hip.pnp_nonlinear_batch_dev(1, d_off.data_ptr(), idx.shape[0], d_uv.data_ptr(), d_x.data_ptr(), d_k.data_ptr(), d_r0.data_ptr(),
-                                    d_c0.data_ptr(), 5.0, 20, hip.QUIRKS_REFERENCE, d_r.data_ptr(), d_c.data_ptr(), d_st.data_ptr(), stream)
+                                    d_c0.data_ptr(), 5.0, 20, hip.QUIRKS_REFERENCE, d_r.data_ptr(), d_c.data_ptr(), d_st.data_ptr(), stream,
+                                    idx.shape[0])
         cams, pts = prob.get_state()                            # synchronises the problem's stream
         torch.cuda.synchronize()
         x_host = np.vstack((pts[:, idx], np.ones((1, idx.shape[0]))))
