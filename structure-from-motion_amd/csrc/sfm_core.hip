@@ -642,7 +642,8 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     pt[5] = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2;
   };
   const bool cached = n <= THREADS * PNP_CACHE;
-  const int staged = (!cached && n <= stage_cap) ? stage_mode : 0;
+  // (the 256-thread variant never stages: its branch-free loop is what views of up to 1 024 points run)
+  const int staged = (THREADS > 256 && !cached && n <= stage_cap) ? stage_mode : 0;
   double pts[PNP_CACHE][6];
   if (cached) {
 #pragma unroll
