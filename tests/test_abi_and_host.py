@@ -173,3 +173,39 @@ def test_observation_tracker_equals_full_rebuild(sfm):
         views.append(v)
     cam_idx = rng.integers(0, 3, 40).astype(np.int32); key_idx = rng.integers(0, 50, 40).astype(np.int32)
     assert np.array_equal(obs.KeyCache().gather_normalised(views, cam_idx, key_idx), obs.gather_normalised_keys(views, cam_idx, key_idx))
+
+
+def test_header_is_plain_c_and_links_from_a_c_program(sfm, tmp_path):
+    """include/sfm_hip.h is the drop-in boundary: it must compile as C (no C++ types, no torch types) and a plain C program
+    must be able to link libsfm_hip.so and call it.  Without a GPU the calls that need one fail with SFM_E_NO_DEVICE and a
+    message -- loudly, never through a CPU path."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "sfm_hip.h"
+int main(void) {
+  double q[4] = {1, 0, 0, 0}, R[9];
+  int st = 0;
+  if (sfm_version() < 100) return 1;
+  int rc = sfm_quat_to_rot(1, q, R, &st);           /* needs a device: SFM_OK on the GPU box, SFM_E_NO_DEVICE here */
+  if (rc != SFM_OK && rc != SFM_E_NO_DEVICE) return 2;
+  if (rc == SFM_E_NO_DEVICE && strlen(sfm_last_error()) == 0) return 3;
+  if (rc == SFM_OK && (R[0] != 1.0 || R[4] != 1.0 || R[8] != 1.0 || st != SFM_OK)) return 4;
+  sfm_ba_problem* p = 0;
+  if (sfm_ba_destroy(p) != SFM_OK) return 5;         /* destroying a null handle is a no-op */
+  printf("abi ok rc=%d\n", rc);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(sfm.native.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe),
+                         "-L", libdir, "-lsfm_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "abi ok" in run.stdout, (run.returncode, run.stdout, run.stderr[-500:])
