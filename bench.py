@@ -672,7 +672,7 @@ class Stopwatch:
         n = self.native
         for name in ("pnp_linear_ransac", "pnp_nonlinear", "triangulate", "tri_nonlinear", "tri_linear", "ba_solve"):
             self.wrap(n, name)
-        for name in ("__init__", "iterate", "get_state", "append", "set_cameras", "set_points", "set_state"):
+        for name in ("__init__", "iterate", "get_state", "get_state_rot", "rederive_quaternions", "append", "set_cameras", "set_points", "set_state"):
             self.wrap(n.BaProblem, name)
 
     def remove(self):

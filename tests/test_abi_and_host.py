@@ -209,3 +209,36 @@ int main(void) {
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and "abi ok" in run.stdout, (run.returncode, run.stdout, run.stderr[-500:])
+
+
+def test_key_cache_gathers_what_the_uncached_path_gathers(sfm):
+    """observations.KeyCache keeps every view's keys (pixels and normalised) between BA calls: whatever order the
+    observations come in, it must return gather_normalised_keys' values bit for bit, and notice a replaced key list or
+    another intrinsic matrix."""
+    obs = sfm.observations
+    rng = np.random.default_rng(11)
+
+    class KP:
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class V:
+        pass
+    views = []
+    for c in range(5):
+        v = V()
+        v.k = np.array([[800.0 + c, 0, 320], [0, 790.0, 240 + c], [0, 0, 1]])
+        v.key_pts = [KP(float(x), float(y)) for x, y in rng.uniform(0, 640, (40, 2))]
+        views.append(v)
+    cache = obs.KeyCache()
+    for order in ("by_point", "runs", "empty"):
+        m = 0 if order == "empty" else 120
+        cam = rng.integers(0, 5, m).astype(np.int32)
+        key = rng.integers(0, 40, m).astype(np.int32)
+        if order == "runs":
+            cam = np.sort(cam)[::-1].copy()                      # a few runs, not ascending
+        assert np.array_equal(cache.gather_normalised(views, cam, key), obs.gather_normalised_keys(views, cam, key))
+    cam = np.repeat(np.arange(5, dtype=np.int32), 8); key = np.tile(np.arange(8, dtype=np.int32), 5)
+    views[2].k = views[2].k * np.array([[1.01], [1.0], [1.0]])                     # another intrinsic matrix
+    views[3].key_pts = [KP(p.pt[0] + 1.0, p.pt[1]) for p in views[3].key_pts]      # another key list
+    assert np.array_equal(cache.gather_normalised(views, cam, key), obs.gather_normalised_keys(views, cam, key))
