@@ -309,7 +309,7 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
     check(lib.sfm_pnp_linear_ransac(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples),
                                     float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
                                     ctypes.byref(best)))
-    return rot, loc.reshape(3, 1), [int(i) for i in np.flatnonzero(mask)], best.value
+    return rot, loc.reshape(3, 1), np.flatnonzero(mask).tolist(), best.value
 
 
 def pnp_six_point_hypotheses(uv_pix, pts_h, intrinsic, samples, threshold):
@@ -338,7 +338,7 @@ def fundamental_ransac(left, right, samples, threshold):
     lib.sfm_fundamental_ransac.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_int, _ip, ctypes.c_double, _dp, _ip, _ip, _ip]
     check(lib.sfm_fundamental_ransac(n, dptr(left), dptr(right), samples.shape[0], iptr(samples), float(threshold),
                                      dptr(fund), iptr(mask), ctypes.byref(cnt), ctypes.byref(best)))
-    inliers = None if best.value < 0 else [int(i) for i in np.flatnonzero(mask[:n])]
+    inliers = None if best.value < 0 else np.flatnonzero(mask[:n]).tolist()
     return fund, inliers, best.value
 
 

@@ -180,8 +180,9 @@ class HipCamposeMixin:
             iteration = self.iteration
         inlier_indices, ini_rot, ini_loc = self.linear_estimate_cam_pose_pnp(
             key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
+        sel = np.asarray(inlier_indices, dtype=np.intp)          # the list is the reference's return type; index with it once
         ref_rot, ref_loc = self.nonlinear_estimate_cam_pose_pnp(
-            key_2d_pts[:, inlier_indices], tri_3d_pts[:, inlier_indices], intrinsic_mat,
+            key_2d_pts[:, sel], tri_3d_pts[:, sel], intrinsic_mat,
             ini_rot, ini_loc, damping_factor, iteration)
         return inlier_indices, ref_rot, ref_loc
 
@@ -195,14 +196,14 @@ class HipCamposeMixin:
     def evalulate_cam_pose_cheirality(self, proj_1, proj_2, tri_3d_pts):
         """Indices of the points in front of both cameras (campose_processor.py:133-189)."""
         mask, _counts, _best = native.cheirality(proj_1, np.asarray(proj_2)[np.newaxis], np.asarray(tri_3d_pts)[np.newaxis])
-        return [int(i) for i in np.flatnonzero(mask[0])]
+        return np.flatnonzero(mask[0]).tolist()
 
     def disambiguate_cam_pose_four(self, ref_proj, projs_four, tri_3d_pts_four):
         """(best_idx, most_valid_indices) of campose_processor.py:102-131: one device call for the four candidates."""
         mask, counts, best = native.cheirality(ref_proj, np.array(projs_four), np.array(tri_3d_pts_four))
         if counts[best] == 0:
             return 0, []
-        return best, [int(i) for i in np.flatnonzero(mask[best])]
+        return best, np.flatnonzero(mask[best]).tolist()
 
 
 class HipEpipolarMixin:
