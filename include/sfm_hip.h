@@ -171,7 +171,10 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets /*[n_views+1]*
                                 const double* d_X /*[4][total]*/, const double* d_K /*[n_views][9]*/, const double* d_R0 /*[n_views][9]*/,
                                 const double* d_C0 /*[n_views][3]*/, double lambda, int iters, int quirks,
                                 double* d_R_out /*[n_views][9]*/, double* d_C_out /*[n_views][3]*/, int* d_status /*[n_views]*/,
-                                int max_view_points /* size of the largest view (the offsets are on the device); 0 = unknown */,
+                                int max_view_points /* size of the largest view (the offsets are on the device); 0 = unknown.
+                                                       Views of up to 1024 points and larger ones run on different kernels, each
+                                                       launched over the whole batch; a truthful value <= 1024 saves the second
+                                                       launch.  A view's result depends on its own size only, never on the batch. */,
                                 void* hip_stream);
 /* X_out[4][n] = (px, py, pz, 1)[index[i]]: the 2D-3D association of ba_processor.py:184-188 (np.take of tri_pts) for points
  * that already live on the device (sfm_ba_points_ptr), so that the per-view PnP uploads keys and indices only. */

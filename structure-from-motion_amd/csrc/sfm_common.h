@@ -117,6 +117,33 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// Row totals of MANY values at once (the 35 normal-equation sums of the PnP kernel): a halving fold instead of N
+// independent group sums.  One step pairs every lane with a partner in the other half of its group; the lane keeps the
+// lower half of the value list if its bit `hi` is clear, the upper half otherwise, and receives the partner's partial sums
+// of exactly those values -- so the list halves while the number of lanes summed doubles.  Four steps (row_mirror split by
+// lane bit 3, row_half_mirror by bit 2, quad xor-2 by bit 1, quad xor-1 by bit 0: each partner agrees with the lane in
+// the bits already used) leave ceil(N / 16) row totals per lane: 35 -> 18 -> 9 -> 5 -> 3 values, 233 instructions where 35
+// four-step sums take 420 (and the compiler keeps each of those a dependent chain).  `fold_index` applies the same
+// selection to the value numbers, once per kernel, so that a lane knows which totals it ends up holding (an odd list
+// leaves its middle value in both lanes of a pair: both then hold, and may store, the same total).
+template <int CTRL, int N>
+__device__ __forceinline__ void fold_half(const double (&v)[N], double (&w)[(N + 1) / 2], bool hi) {
+  constexpr int H = (N + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < N - H; ++k) {
+    const double keep = hi ? v[k + H] : v[k], send = hi ? v[k] : v[k + H];
+    w[k] = keep + dpp_f64<CTRL>(send);
+  }
+  if (N & 1) w[H - 1] = v[H - 1] + dpp_f64<CTRL>(v[H - 1]);
+}
+template <int N>
+__device__ __forceinline__ void fold_index(const int (&v)[N], int (&w)[(N + 1) / 2], bool hi) {
+  constexpr int H = (N + 1) / 2;
+#pragma unroll
+  for (int k = 0; k < N - H; ++k) w[k] = hi ? v[k + H] : v[k];
+  if (N & 1) w[H - 1] = v[H - 1];
+}
+
 // 1/sqrt(d) to full double precision: v_rsq_f64 seed (5e-8) + ONE third-order step r (1 + e/2 + 3 e^2 / 8),
 // e = 1 - d r^2: five operations where two Newton steps take seven, and closer -- 1.4e-16 against 2.4e-16 maximal
 // relative error (tools/microbench_solve.hip).  (sqrt / division expand to ~50 dependent instructions each.)

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
                                                                 const double* __restrict__ C0, double lambda, int iters,
                                                                 int quirks, double* __restrict__ R_out,
                                                                 double* __restrict__ C_out, int* __restrict__ status,
-                                                                int stage_mode, int stage_cap) {
+                                                                int stage_mode, int stage_cap, int n_lo, int n_hi) {
   // Views too large for the register cache keep their points in LDS when they fit (stage_mode 1: X, Y, Z, W and the
   // normalised key, 48 bytes per point, SoA over stage_cap points; 2: the normalised key only, the point is re-read from
   // L2): the key normalisation -- two divisions per point -- is then done once, not in every iteration.
@@ -605,6 +605,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
   const int view = blockIdx.x;
   const int base = offsets[view];
   const int n = offsets[view + 1] - base;
+  if (n < n_lo || n > n_hi) return;          // the other size class' launch refines this view (enqueue_pnp_nonlinear)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
 
@@ -664,6 +665,18 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     __syncthreads();
   }
 
+  // which three of the 35 sums this lane holds after the fold of an iteration
+  int own[3];
+  {
+    int i35[35], i18[18], i9[9], i5[5];
+#pragma unroll
+    for (int k = 0; k < 35; ++k) i35[k] = k;
+    fold_index(i35, i18, (lane & 8) != 0);
+    fold_index(i18, i9, (lane & 4) != 0);
+    fold_index(i9, i5, (lane & 2) != 0);
+    fold_index(i5, own, (lane & 1) != 0);
+  }
+
   for (int it = 0; it < iters && st == SFM_OK; ++it) {
     double acc[35];
 #pragma unroll
@@ -716,13 +729,16 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
         accumulate(pt, p);
       }
     }
-    // 35 sums over the workgroup: four DPP steps leave the total of every 16-lane row in all of its lanes; the rows'
-    // totals go to LDS (one store instruction per value, four lanes active) and 35 threads add the 4 x WAVES partials --
-    // the two further cross-row steps per value would cost a third of the reduction's ~630 issue slots per wave
+    // 35 sums over the workgroup: a four-step halving fold (fold_half, sfm_common.h) leaves three of the 35 totals of a
+    // 16-lane row in each of its lanes; they go to LDS and 35 threads add the 4 x WAVES row partials
+    {
+      double f18[18], f9[9], f5[5], f3[3];
+      fold_half<0x140>(acc, f18, (lane & 8) != 0);
+      fold_half<0x141>(f18, f9, (lane & 4) != 0);
+      fold_half<0x4E>(f9, f5, (lane & 2) != 0);
+      fold_half<0xB1>(f5, f3, (lane & 1) != 0);
 #pragma unroll
-    for (int k = 0; k < 35; ++k) {
-      const double s = group_sum<16>(acc[k]);
-      if ((lane & 15) == 15) red[4 * wave + (lane >> 4)][k] = s;
+      for (int j = 0; j < 3; ++j) red[4 * wave + (lane >> 4)][own[j]] = f3[j];
     }
     __syncthreads();
     if (tid < 35) {
@@ -919,23 +935,33 @@ __global__ void gather_points_kernel(int n, const int* __restrict__ index, const
 
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
-                                 double* R_out, double* C_out, int* status, hipStream_t s, int widest) {
-  // `widest`: the largest view (the host entry point knows its offsets; the device-pointer form passes twice the mean).  Up to
-  // 1024 points 256 threads keep four points each in registers; beyond that 512 threads work out of LDS: all six values of
-  // a point up to 3 200 points (150 KB), the normalised key alone up to 9 600, nothing beyond (a view above the capacity
-  // of the chosen mode falls back to re-reading inside the kernel).
-  if (widest <= 1024) {
-    pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, 0, 0);
-  } else {
+                                 double* R_out, double* C_out, int* status, hipStream_t s, int narrowest, int widest) {
+  // Two size classes, each with its own launch over all views (a workgroup whose view belongs to the other class returns at
+  // once), so that the kernel a view runs on -- and with it every bit of its result -- depends on the view's own size and
+  // not on what else is in the batch (a shard of a batch returns what the whole batch returns):
+  //   up to 1024 points   256 threads keep four points each in registers;
+  //   above               512 threads work out of LDS: all six values of a point up to 3 200 points (150 KB), the
+  //                       normalised key alone up to 9 600, nothing beyond (a view above the capacity of the chosen mode
+  //                       re-reads its points inside the kernel; the staging changes where values come from, not the values).
+  // `narrowest` / `widest`: the smallest and the largest view when the caller knows them (the host entry point has the
+  // offsets), 0 = unknown.  A class no view can be in is not launched.
+  constexpr int kSmall = 1024, kAll = 0x7fffffff;
+  const bool small_class = narrowest <= kSmall;
+  const bool big_class = widest <= 0 || widest > kSmall;
+  if (small_class)
+    pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, 0, 0,
+                                                         0, big_class ? kSmall : kAll);
+  if (big_class) {
     static const bool attr = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_nonlinear_kernel<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       return true;
     }();
     (void)attr;
-    const int mode = widest <= 3200 ? 1 : (widest <= 9600 ? 2 : 0);
+    const int mode = widest <= 0 ? 2 : (widest <= 3200 ? 1 : (widest <= 9600 ? 2 : 0));
     const int cap = mode == 1 ? 3200 : (mode == 2 ? 9600 : 0);
     const size_t lds = sizeof(double) * (size_t)cap * (mode == 1 ? 6 : 2);
-    pnp_nonlinear_kernel<512, 2><<<n_views, 512, lds, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, mode, cap);
+    pnp_nonlinear_kernel<512, 2><<<n_views, 512, lds, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, mode, cap,
+                                                          small_class ? kSmall + 1 : 0, kAll);
   }
   SFM_HIP(hipGetLastError());
   return SFM_OK;
@@ -1145,11 +1171,10 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, co
     set_error("sfm_pnp_nonlinear_batch_dev: null device pointer");
     return SFM_E_SHAPE;
   }
-  // the offsets live on the device: the caller says how large its largest view is (0: unknown -- the mean stands in; a
-  // view above what the chosen variant keeps on chip is still correct, it re-reads its points every iteration)
-  const int widest = max_view_points > 0 ? max_view_points : (int)((long long)total / n_views);
+  // the offsets live on the device: the caller says how large its largest view is (0: unknown -- both size classes are
+  // launched; a view larger than the caller said is still refined, by the small-view kernel re-reading its points)
   SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
-                                d_C_out, d_status, pick_stream(hip_stream), widest));
+                                d_C_out, d_status, pick_stream(hip_stream), 0, max_view_points > 0 ? max_view_points : 0));
   return SFM_OK;
 }
 
@@ -1309,10 +1334,13 @@ int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const do
   SFM_TRY(dK.upload(K, 9 * (size_t)n_views, s)); SFM_TRY(dR0.upload(R0, 9 * (size_t)n_views, s));
   SFM_TRY(dC0.upload(C0, 3 * (size_t)n_views, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_views)); SFM_TRY(dC.alloc(3 * (size_t)n_views)); SFM_TRY(dSt.alloc(n_views));
-  int widest = 0;
-  for (int v = 0; v < n_views; ++v) widest = std::max(widest, offsets[v + 1] - offsets[v]);
+  int widest = 0, narrowest = 0x7fffffff;
+  for (int v = 0; v < n_views; ++v) {
+    widest = std::max(widest, offsets[v + 1] - offsets[v]);
+    narrowest = std::min(narrowest, offsets[v + 1] - offsets[v]);
+  }
   SFM_TRY(enqueue_pnp_nonlinear(n_views, dOff.p, total, dUV.p, dX.p, dK.p, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p,
-                                dSt.p, s, widest));
+                                dSt.p, s, narrowest, std::max(widest, 1)));
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_views, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_views, s));
   SFM_TRY(dSt.download(status, n_views, s));
   SFM_TRY(stream_sync(s));
