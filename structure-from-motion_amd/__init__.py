@@ -11,10 +11,11 @@ csrc/          hand-written HIP kernels (gfx950) + the C-ABI (include/sfm_hip.h)
 native.py      ctypes binding of the C-ABI; raises if the library is missing (no CPU fallback)
 processors.py  drop-in mirrors of the reference's *_processor classes for the hot path
 observations.py  KeyTrack tables -> observation CSR with the reference's is_visible semantics
+sampling.py    RANSAC subsets from Python's RNG stream, drawn in bulk with random.sample's exact consumption
 sharding.py    point-range sharding of BA across ranks (one process per GPU, RCCL all-reduce)
 geometry.py    host-side q<->R helpers (camera block packing, reference exceptions)
 scenes.py      seeded synthetic scenes of BASELINE.json's configs
 """
-from . import geometry, native, observations, processors, scenes, sharding  # noqa: F401
+from . import geometry, native, observations, processors, sampling, scenes, sharding  # noqa: F401
 
-__all__ = ["geometry", "native", "observations", "processors", "scenes", "sharding"]
+__all__ = ["geometry", "native", "observations", "processors", "sampling", "scenes", "sharding"]

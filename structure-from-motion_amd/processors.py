@@ -30,6 +30,7 @@ import numpy as np
 from . import native
 from .geometry import (pack_cameras, quaternion_to_rotation_unchecked, quaternions_to_rotations)
 from .observations import KeyCache, ObservationTracker, build_observations, gather_normalised_keys
+from .sampling import sample_indices
 
 
 # ------------------------------------------------------------------------------------------------
@@ -152,8 +153,7 @@ class HipCamposeMixin:
     def linear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config=None):
         """RANSAC 6-point DLT PnP (campose_processor.py:249-305, 485-633).  The six-point samples are drawn
         here with ``random.sample`` exactly as the reference does (same consumption of Python's global RNG
-        stream, campose:531); every hypothesis is solved and scored on the device."""
-        import random
+        stream, campose:531; ``sampling.sample_indices`` draws them in bulk); every hypothesis is solved and scored on the device."""
         if not ransac_config:
             ransac_config = self.ransac_config
         if key_2d_pts.shape[1] != tri_3d_pts.shape[1]:
@@ -165,7 +165,7 @@ class HipCamposeMixin:
         if num_pts < 6:
             logging.warning('%s : required equal or more than six points %d', self.__class__.__name__, num_pts)
             raise ValueError("required equal or more than six points {}".format(num_pts))
-        samples = [random.sample(range(num_pts), 6) for _ in range(ransac_config.iteration)]
+        samples = sample_indices(num_pts, 6, ransac_config.iteration, as_array=True)       # = [random.sample(range(num_pts), 6) ...], campose:531
         rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
             key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
         return inlier_indices, rot, loc
@@ -211,7 +211,6 @@ class HipEpipolarMixin:
     on the device.  Expects ``self.ransac``; sets ``self.fund_mat`` / ``self.esse_mat`` as the reference does."""
 
     def determine_fundamental_mat(self, matched_pairs, ransac_config=None):
-        import random
         cfg = self.ransac if ransac_config is None else ransac_config
         left, right = np.asarray(matched_pairs[0]), np.asarray(matched_pairs[1])
         rows = left.shape[1]
@@ -219,7 +218,7 @@ class HipEpipolarMixin:
             logging.error('%s : number of matched pairs needs equal or more than eight')
             raise ValueError("Insufficient matched pairs : {}".format(rows))
         # same consumption of Python's global RNG stream as epipolar:225 (no draw when rows == 8)
-        samples = None if rows == 8 else [random.sample(range(rows), 8) for _ in range(cfg.iteration)]
+        samples = None if rows == 8 else sample_indices(rows, 8, cfg.iteration, as_array=True)
         fund, inliers, _best = native.fundamental_ransac(left, right, samples, cfg.inlier_threshold)
         self.fund_mat = fund
         return inliers

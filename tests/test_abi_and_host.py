@@ -242,3 +242,28 @@ def test_key_cache_gathers_what_the_uncached_path_gathers(sfm):
     views[2].k = views[2].k * np.array([[1.01], [1.0], [1.0]])                     # another intrinsic matrix
     views[3].key_pts = [KP(p.pt[0] + 1.0, p.pt[1]) for p in views[3].key_pts]      # another key list
     assert np.array_equal(cache.gather_normalised(views, cam, key), obs.gather_normalised_keys(views, cam, key))
+
+
+def test_bulk_ransac_samples_replay_random_sample_exactly(sfm):
+    """sampling.sample_indices must return what ``[random.sample(range(n), k) for _ in range(count)]`` returns on the same
+    generator AND leave the generator where that leaves it (the reference's later draws depend on it:
+    campose_processor.py:531, epipolar_processor.py:225) -- populations with many duplicate re-draws, power-of-two
+    boundaries, the small-population branch, the global generator."""
+    import random
+    sampling = sfm.sampling
+    cases = [(5000, 6, 300), (86, 6, 300), (87, 8, 120), (128, 6, 100), (129, 6, 100), (255, 8, 64), (256, 8, 64), (4097, 6, 11),
+             (40, 6, 50), (85, 6, 30), (8, 8, 20), (600, 6, 300), (2 ** 31 + 5, 6, 20), (2 ** 33, 6, 20), (1000, 6, 3)]
+    for seed, (n, k, count) in enumerate(cases):
+        a, b = random.Random(seed), random.Random(seed)
+        got = sampling.sample_indices(n, k, count, rng=a)
+        want = [b.sample(range(n), k) for _ in range(count)]
+        assert got == want, (n, k, count)
+        assert all(type(i) is int for i in got[0])
+        assert a.getstate() == b.getstate(), (n, k, count)
+    random.seed(-1)                                           # utils.py:129-174 seeds the global generator like this
+    got = sampling.sample_indices(3000, 6, 300)
+    after = random.random()
+    random.seed(-1)
+    want = [random.sample(range(3000), 6) for _ in range(300)]
+    assert got == want and random.random() == after
+    assert sampling._verified is True                         # the bulk path is what ran, not the fallback
