@@ -654,7 +654,7 @@ class Stopwatch:
     """Accumulates the wall time spent inside the native (C-ABI) calls of one stage."""
 
     def __init__(self, native):
-        self.native, self.t, self._saved = native, 0.0, []
+        self.native, self.t, self._saved, self.by_name = native, 0.0, [], {}
 
     def wrap(self, obj, name):
         fn = getattr(obj, name)
@@ -664,7 +664,9 @@ class Stopwatch:
             try:
                 return fn(*a, **k)
             finally:
-                self.t += time.perf_counter() - t0
+                dt = time.perf_counter() - t0
+                self.t += dt
+                self.by_name[name] = self.by_name.get(name, 0.0) + dt
         self._saved.append((obj, name, fn))
         setattr(obj, name, timed)
 
@@ -682,6 +684,7 @@ class Stopwatch:
 
     def take(self):
         t, self.t = self.t, 0.0
+        self.last_by_name, self.by_name = self.by_name, {}
         return t
 
 
@@ -761,6 +764,7 @@ def run_c5(args, ctx):
             bp._BaProcessor__execute_bundle_adjustment()                                            # ba_processor.py:267
             stage["ba_s"] = time.perf_counter() - t0
             stage["ba_native_s"] = sw.take()
+            stage["ba_native_calls_ms"] = {k: round(v * 1e3, 4) for k, v in sw.last_by_name.items()}
             stage["ba_action"], stage["ba_upload_bytes"] = bp.ba_last_action, bp.ba_upload_bytes - before
             stage["view_s"] = stage.get("pnp_s", 0.0) + stage["triangulate_s"] + stage["ba_s"]      # the three drop-in calls of ba_processor.py:191, 246, 267
             stage["harness_s"] = time.perf_counter() - t_view - stage["view_s"]                     # stand-in for the front end / track bookkeeping: not timed
@@ -792,6 +796,7 @@ def run_c5(args, ctx):
         rows = [r[i] for r in records]
         agg = {k: float(np.median([r[k] for r in rows])) for k in rows[0] if k.endswith("_s")}
         agg.update({k: rows[0][k] for k in ("views", "points", "observations", "ba_action", "ba_upload_bytes")})
+        agg["ba_native_calls_ms"] = {k: float(np.median([r["ba_native_calls_ms"].get(k, 0.0) for r in rows])) for k in rows[0]["ba_native_calls_ms"]}
         agg["host_python_s"] = agg["view_s"] - sum(agg.get(k, 0.0) for k in ("pnp_native_s", "triangulate_native_s", "ba_native_s"))
         per_view.append(agg)
     out = {

@@ -85,6 +85,7 @@ class ObservationTracker:
 
     def __init__(self):
         self.rows = []          # copies of the self rows as of the last reset / diff
+        self.row_max = []       # per view: an upper bound of the ids in its cached row
         self.seen = []          # per view: bool (capacity,) -- points the view observes
         self.n_pts = 0
 
@@ -93,6 +94,7 @@ class ObservationTracker:
         out = build_observations(self_rows, n_pts)
         _pt_ptr, cam_idx, pt_idx, _key_idx = out
         self.rows = [np.array(r, copy=True) for r in self_rows]
+        self.row_max = [int(r.max()) if r.size else -1 for r in self.rows]
         self.n_pts = int(n_pts)
         self.seen = []
         for c in range(len(self_rows)):
@@ -124,7 +126,7 @@ class ObservationTracker:
                 if np.any((was >= 0) & (was < old_n_pts)):          # an entry that contributed an observation changed
                     return None
             cand = chg
-            if n_pts > old_n_pts:                                    # ids that were out of range before and are points now
+            if n_pts > old_n_pts and self.row_max[c] >= old_n_pts:   # ids that were out of range before and are points now
                 late = np.flatnonzero((cached >= old_n_pts) & (cached < n_pts) & (row == cached))
                 if late.size:
                     cand = np.union1d(chg, late)
@@ -148,9 +150,12 @@ class ObservationTracker:
         self._grow_seen(n_pts)
         for c in range(n_old_views):
             if changes[c].size:
-                self.rows[c][changes[c]] = np.asarray(self_rows[c])[changes[c]]
+                vals = np.asarray(self_rows[c])[changes[c]]
+                self.rows[c][changes[c]] = vals
+                self.row_max[c] = max(self.row_max[c], int(vals.max()))
         for c in range(n_old_views, len(self_rows)):
             self.rows.append(np.array(self_rows[c], copy=True))
+            self.row_max.append(int(self.rows[-1].max()) if self.rows[-1].size else -1)
             self.seen.append(np.zeros(max(n_pts, 1), dtype=bool))
         self.n_pts = int(n_pts)
         if not cams:
