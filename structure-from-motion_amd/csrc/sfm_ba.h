@@ -8,7 +8,8 @@
 
 namespace sfm {
 
-// Camera row blocks of the dense Schur product (sfm_ba_schur.hip): CB cameras = 126 rows, padded to RB = 128.
+// Blocks of the Schur products (sfm_ba_schur.hip): the sparse tiles hold CB whole cameras = 126 rows in an RB = 128 pitch;
+// the dense product cuts the rows of S into blocks of RB regardless of cameras.
 constexpr int kSchurCB = 18;
 constexpr int kSchurRB = 128;
 constexpr int kSchurKSL = 16;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
@@ -63,9 +64,9 @@ struct BaDev {
   // per-iteration scratch
   CamPrep* prep[2] = {nullptr, nullptr};   // double-buffered: back-substitution still needs the old one
   double* Z = nullptr;      // [M][21] (AoS)  Z_o = (Jp^T Jx) L_p^-T, element e = 3*i + j; sparse-product path only (lazy)
-  double* Zd = nullptr;     // [zrows][zp] dense Z^T for the MFMA product: row 3p + j, column 128*(cam/18) + 7*(cam%18) + i;
+  double* Zd = nullptr;     // [zrows][zp] dense Z^T for the MFMA product: row 3p + j, column 7 cam + i (= the row of S);
                             // entries of invisible (point, camera) pairs and all padding stay zero for the problem's lifetime
-  int zp = 0;               // row pitch of Zd = 128 * ceil(V / 18)
+  int zp = 0;               // row pitch of Zd = 7 V rounded up to a multiple of 16 (the MFMA strip)
   int zrows = 0;            // 3N rounded up to a multiple of kSchurKSL
   double* lin_ws = nullptr; // [linearize workgroups][V][35] per-workgroup camera accumulators (U lower 28 | rhs 7)
   double* red = nullptr;    // [red_size(nbk)] reduced system S (lower-triangular 32x32 blocks) | rhs

@@ -205,8 +205,7 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
         m1[1] = Jx[3] * li[1] + Jx[4] * li[2];
         m1[2] = Jx[3] * li[3] + Jx[4] * li[4] + Jx[5] * li[5];
         if (DENSE_Z) {
-          const int blk = cam / kSchurCB;
-          double* zr = d.Zd + (size_t)(3 * p) * d.zp + blk * kSchurRB + 7 * (cam - blk * kSchurCB);
+          double* zr = d.Zd + (size_t)(3 * p) * d.zp + 7 * cam;
           // 7 consecutive doubles per row, 8-byte aligned: three 16-byte stores + one 8-byte store per row
           // (12 write requests per observation instead of 21; the request rate bounds this kernel's tail)
           typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));

@@ -22,9 +22,11 @@ namespace sfm {
 // Dense MFMA product  S(lower) -= Zd^T Zd  over the materialised Z.
 //
 // ba_linearize writes every observation's 7x3 block Z_o into the dense matrix Zd[3N][zp] (row 3p + j, column
-// 128 * (cam / 18) + 7 * (cam % 18) + i; zeros where the point is not seen): cameras are grouped into column
-// blocks of CB = 18 (126 columns, padded to RB = 128 = 8 MFMA strips), so block boundaries never cut a
-// camera and a block's panel row is 1 KiB of contiguous memory.  The product is then a plain split-K SYRK:
+// 7 cam + i = the row of S; zeros where the point is not seen; zp = 7V rounded up to the 16-row MFMA strip).  The
+// columns are cut into blocks of RB = 128 (8 strips; the last block may hold fewer), a block's panel row is 1 KiB of
+// contiguous memory.  (Rounds 1-3 grouped 18 whole cameras = 126 columns into every 128: at 50 cameras 276 MFMA tiles
+// per k-step instead of the 253 of the 22 strips that 350 rows need.  Only the reduce has to know that a block
+// boundary cuts through a camera: it maps elements, not blocks.)  The product is then a plain split-K SYRK:
 // grid = (lower-triangular 128x128 output tiles) x (row chunks of Zd); one workgroup = 8 waves.
 //   * staging: one  global_load_lds_dwordx4  per wave copies one 1 KiB panel row straight into the
 //     [k][ZLD] LDS image (no VGPRs, no FP64-pipe work); 16 rows x (1 or 2) panels per slab in a ring of 4
@@ -250,9 +252,10 @@ __device__ __forceinline__ void schur_tile_body(const double* __restrict__ Zd, s
   }
 }
 
-// Work split of both products.  Tiles are the lower-triangular pairs of 18-camera blocks, in four classes with
+// Work split of both products.  Tiles are the lower-triangular pairs of blocks (128 rows of S in the dense product, 18
+// whole cameras in the sparse one), in four classes with
 // their own chunking: off-diagonal tiles (ti > tj, row-major order) whose row block is full, off-diagonal tiles
-// of the LAST block (which may hold fewer than 18 cameras: its empty 16-row MFMA strips are skipped), full
+// of the LAST block (which may be partly empty: its empty 16-row MFMA strips are skipped), full
 // diagonal tiles and the last diagonal tile.  A dense off-diagonal tile issues 2 x (strips of its row block)
 // MFMAs per SIMD and k-step (16 when full), a diagonal one the larger half of its lower sub-tiles (9 when full);
 // rows per chunk are inversely proportional, so every workgroup carries the same MFMA load.  Workgroup w's
@@ -262,6 +265,8 @@ struct SchurPlan {
   int chunks[4], rpc[4];        // per class (0 off full, 1 off last row, 2 diag full, 3 diag last): chunks per tile,
                                 // rows of Zd (dense) or points (sparse) per chunk
   int ra_last;                  // 16-row strips of the last block that hold cameras (1..8)
+  int cam_blocks;               // 1: blocks of 18 whole cameras, block row r = camera 18 b + r / 7 (sparse tiles);
+                                // 0: blocks of 128 consecutive rows of S, block row r = row 128 b + r (dense product)
   int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
 };
 
@@ -472,11 +477,9 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BaDev d, const dou
   const SchurTileRef tr = plan_tile(plan, tile);
   const int ti = tr.ti, tj = tr.tj, first = tr.first, chunks = plan.chunks[tr.cls];
   const int r = e / RB, c = e - r * RB;
-  if (r >= 7 * CB || c >= 7 * CB) return;
-  const int cam_r = ti * CB + r / 7, cam_c = tj * CB + c / 7;
-  if (cam_r >= d.V || cam_c >= d.V) return;
-  const int row = 7 * cam_r + r % 7, col = 7 * cam_c + c % 7;
-  if (col > row) return;
+  if (plan.cam_blocks && (r >= 7 * CB || c >= 7 * CB)) return;
+  const int row = (plan.cam_blocks ? 7 * CB : RB) * ti + r, col = (plan.cam_blocks ? 7 * CB : RB) * tj + c;
+  if (row >= d.P || col > row) return;
   const int per = (chunks + gridDim.y - 1) / gridDim.y;
   const int k0 = blockIdx.y * per, k1 = min(chunks, k0 + per);
   double s = 0;
@@ -512,17 +515,15 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_det_kernel(BaDev d, const
   const SchurTileRef tr = plan_tile(plan, tile);
   const int ti = tr.ti, tj = tr.tj, first = tr.first, chunks = plan.chunks[tr.cls];
   const int r = e / RB, c = e - r * RB;
-  if (r >= 7 * CB || c >= 7 * CB) return;
-  const int cam_r = ti * CB + r / 7, cam_c = tj * CB + c / 7;
-  if (cam_r >= d.V || cam_c >= d.V) return;
-  const int row = 7 * cam_r + r % 7, col = 7 * cam_c + c % 7;
-  if (col > row) return;
+  if (plan.cam_blocks && (r >= 7 * CB || c >= 7 * CB)) return;
+  const int row = (plan.cam_blocks ? 7 * CB : RB) * ti + r, col = (plan.cam_blocks ? 7 * CB : RB) * tj + c;
+  if (row >= d.P || col > row) return;
   double s = 0;
   for (int k = 0; k < chunks; ++k) s += ws[(size_t)(first + k) * (RB * RB) + e];
   double u = 0;
-  if (cam_r == cam_c) {
-    const int i = r % 7, j = c % 7;
-    const int t = cam_r * 35 + i * (i + 1) / 2 + j;
+  if (row / 7 == col / 7) {
+    const int i = row % 7, j = col % 7;
+    const int t = (row / 7) * 35 + i * (i + 1) / 2 + j;
     for (int q = 0; q < lin_rows; ++q) u += d.lin_ws[(size_t)q * d.V * 35 + t];
   }
   d.red[red_index(row, col)] = u - s;
@@ -541,12 +542,18 @@ static int diag_cost(int ra) {
   return std::max(1, worst);
 }
 
+static int schur_dense_width(int V) { return std::max(16, ((7 * V + 15) / 16) * 16); }
+
 static SchurPlan make_plan(const BaDev& d) {
   SchurPlan pl;
   pl.dbg = 0;
-  pl.nblk = (d.V + CB - 1) / CB;
+  // the columns of Zd are the rows of S themselves (camera c, parameter i -> 7 c + i), padded to a multiple of the
+  // 16-row MFMA strip; 128-row blocks cut through cameras, which only the reduce has to know (it maps elements)
+  const int width = schur_dense_width(d.V);
+  pl.cam_blocks = 0;
+  pl.nblk = (width + RB - 1) / RB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
-  pl.ra_last = (7 * (d.V - (pl.nblk - 1) * CB) + 15) / 16;
+  pl.ra_last = (width - (pl.nblk - 1) * RB) / 16;
   const int slabs = std::max(1, d.zrows / KSL);
   // ONE workgroup per CU in total (each needs 144 KB of LDS, so a CU hosts one at a time): a single even
   // round pays the per-workgroup prologue / slab write once.  Rows per chunk are inversely proportional to the
@@ -576,6 +583,7 @@ static SchurPlan make_pairs_plan(const BaDev& d) {
   pl.nblk = (d.V + CB - 1) / CB;
   pl.n_off = pl.nblk * (pl.nblk - 1) / 2;
   pl.ra_last = 8;
+  pl.cam_blocks = 1;
   const int ntiles = pl.n_off + pl.nblk;
   int chunks = std::max(1, 2 * ctx().num_cus / ntiles);
   chunks = std::max(1, std::min(chunks, (d.N + PAIR_WAVES - 1) / PAIR_WAVES));
@@ -590,7 +598,7 @@ static SchurPlan make_pairs_plan(const BaDev& d) {
 // use by ba_schur_prepare_dense.
 int ba_schur_plan(sfm_ba_problem* p) {
   BaDev& d = p->dev;
-  d.zp = RB * ((d.V + CB - 1) / CB);
+  d.zp = schur_dense_width(d.V);
   d.zrows = ((3 * d.N + KSL - 1) / KSL) * KSL;
   const SchurPlan pl = make_plan(d);
   const SchurPlan pp = make_pairs_plan(d);
@@ -598,7 +606,7 @@ int ba_schur_plan(sfm_ba_problem* p) {
   const int wgs_pairs = plan_wgs(pp);
   const size_t ws_dense = sizeof(double) * (size_t)wgs * RB * RB;
   const size_t ws_pairs = sizeof(double) * (size_t)wgs_pairs * RB * RB;
-  const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
+  const size_t zd_bytes = sizeof(double) * ((size_t)d.zrows * d.zp + RB);
   // the dense path is only ever chosen when it is cheaper than the pair path; do not reserve
   // tens of gigabytes for scenes that will never take it
   p->schur_mfma_ok = d.N > 0 && ws_dense + zd_bytes <= ((size_t)32 << 30);
@@ -618,7 +626,10 @@ int ba_schur_plan(sfm_ba_problem* p) {
 int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
   BaDev& d = p->dev;
   if (d.Zd != nullptr) return SFM_OK;
-  const size_t zd_bytes = sizeof(double) * (size_t)d.zrows * d.zp;
+  // + RB: the staging loads of a panel are 128 columns wide whatever the last block holds, so the panel of the last
+  // block reads up to 128 - 16 ra_last columns into the NEXT row of Zd -- values that only feed strips nobody computes --
+  // and, for the last row, that far past it
+  const size_t zd_bytes = sizeof(double) * ((size_t)d.zrows * d.zp + RB);
   SFM_HIP(pool_alloc(reinterpret_cast<void**>(&d.Zd), zd_bytes));
   SFM_HIP(hipMemsetAsync(d.Zd, 0, zd_bytes, s));
   return SFM_OK;
@@ -628,7 +639,7 @@ int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s) {
 // SFM_SCHUR_PAIRS (sparse, 18-camera tiles).  AUTO compares three cost models fitted on MI355X (profiles/r2n for the large
 // scenes; round 3 refitted the constants on 6-30 cameras, profiles/r3/time_small.txt, where round 2's "+15 us" for the dense
 // product made AUTO pick the tiles although the dense kernel was 2-15 us faster from nine cameras on):
-//   dense   ~29 T MAC/s of its (64 off-diagonal + 36 diagonal MFMA tiles) x 256 x 3N MACs + 4 us
+//   dense   ~29 T MAC/s of its s (s + 1) / 2 MFMA tiles (s = ceil(7V / 16) strips) x 256 x 3N MACs + 4 us
 //   tiles   ~0.65 ns per (point, tile) visit + ~0.7 ps per LDS add + the split-K slabs' write and re-read (one used tile per
 //           workgroup at ~8 TB/s) + 4 us   (C4 share: 975 k visits, 285 M adds -> 0.63 ms; 20 x 3000 @ 0.3: 510 workgroups
 //           flushing 126 x 126 tiles -> 22 us against the dense kernel's 6)
@@ -645,7 +656,8 @@ int ba_schur_choice(const sfm_ba_problem* p) {
   if (d.N == 0 || d.M == 0) return SFM_SCHUR_PAIRS;
   const double nblk = (double)((d.V + CB - 1) / CB);
   const double kbar = (double)d.M / d.N;
-  const double dense_s = (0.5 * nblk * (nblk - 1) * 64.0 + nblk * 36.0) * 256.0 * 3.0 * d.N / 29e12 + 4e-6;
+  const double strips = schur_dense_width(d.V) / 16.0;                          // lower-triangular 16 x 16 MFMA tiles
+  const double dense_s = 0.5 * strips * (strips + 1.0) * 256.0 * 3.0 * d.N / 29e12 + 4e-6;
   const double nocc = nblk * (1.0 - std::pow(1.0 - 1.0 / nblk, kbar));            // occupied blocks per point
   const double visits = 0.5 * nocc * (nocc + 1.0) * d.N;
   const double pairs = 0.5 * kbar * (kbar + 1) * d.N;
