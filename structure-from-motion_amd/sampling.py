@@ -91,8 +91,12 @@ def sample_indices(n, k, count, rng=None, as_array=False):
     """``[random.sample(range(n), k) for _ in range(count)]`` -- same lists, same generator state afterwards.
     ``rng``: a ``random.Random`` (default: the module-level generator the reference uses); ``as_array``: return the
     samples as an int32 array (count, k) instead of a list of lists."""
-    rng = random._inst if rng is None else rng
     n, k, count = int(n), int(k), int(count)
+    if rng is None:
+        rng = getattr(random, "_inst", None)          # the hidden generator behind random.sample / random.seed (CPython)
+        if rng is None:                               # another implementation of the module: its own sample, one by one
+            out = [random.sample(range(n), k) for _ in range(count)]
+            return np.asarray(out, dtype=np.int32).reshape(count, k) if as_array else out
     # below ~400 items so many samples re-draw a duplicate (15 / n of them for k = 6) that the replay is no faster
     if (count * k < 64 or n < max(400, _setsize(k) + 1) or n.bit_length() > 32 or type(rng).getrandbits is not random.Random.getrandbits
             or not _self_check()):
