@@ -438,13 +438,15 @@ class HipBaMixin:
 
         if self.ba_verbose:                                                                    # ba:418-439
             from scipy.spatial.transform import Rotation
+            # (the reference converts its packed quaternions back: R(q(R)) == R to rounding; all views in two calls --
+            # one Rotation object per view costs ~0.1 ms each, more than the device spends on a small scene)
+            init_angles = Rotation.from_matrix(init_rots).as_euler('zyx', degrees=True).reshape(view_num, 3)
+            refi_angles = Rotation.from_matrix(np.stack([quaternion_to_rotation_unchecked(cams[v, 3:7]) for v in range(view_num)])
+                                               ).as_euler('zyx', degrees=True).reshape(view_num, 3)
             for view_idx in range(view_num):
                 diff_loc = math.sqrt(np.sum(np.square(init_locs[view_idx] - cams[view_idx, 0:3])))
                 print('DEBUG: {}-th view loc distance changes {} unit'.format(view_idx, diff_loc))
-                # (the reference converts its packed quaternions back: R(q(R)) == R to rounding)
-                init_angle = Rotation.from_matrix(init_rots[view_idx]).as_euler('zyx', degrees=True)
-                refi_angle = Rotation.from_matrix(quaternion_to_rotation_unchecked(cams[view_idx, 3:7])).as_euler('zyx', degrees=True)
-                print('DEBUG: {}-th view angles changes {} degree'.format(view_idx, np.abs(init_angle - refi_angle)))
+                print('DEBUG: {}-th view angles changes {} degree'.format(view_idx, np.abs(init_angles[view_idx] - refi_angles[view_idx])))
             moved = np.sqrt(np.sum(np.square(init_tri_pts - pts), axis=0))
             for tri_idx in np.flatnonzero(moved >= 5):
                 print('DEBUG: {}-th pt loc changes more than 5 unit, {} unit'.format(tri_idx, moved[tri_idx]))
