@@ -9,8 +9,15 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 TOL = 1e-9
-SETTINGS = dict(max_examples=120, deadline=None, database=None, derandomize=True,
+# The default run replays the same derandomised examples (a failure must reproduce on the next box).  Exploration runs:
+# SFM_HYPOTHESIS_RANDOM=1 draws fresh examples, SFM_HYPOTHESIS_EXAMPLES=<n> sets how many of them per test
+# (tools/gpu_explore.sh; SFM_TRACE_EXAMPLES keeps what was drawn).
+_RANDOM = os.environ.get("SFM_HYPOTHESIS_RANDOM", "") not in ("", "0")
+_EXAMPLES = int(os.environ.get("SFM_HYPOTHESIS_EXAMPLES", "0"))
+SETTINGS = dict(max_examples=_EXAMPLES or 120, deadline=None, database=None, derandomize=not _RANDOM,
                 suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
@@ -54,7 +61,7 @@ def test_ba_random_scene_matches_oracle(hip, oracle, sfm, args, lam, iters, mode
     assert np.max(np.abs(np.linalg.norm(cams[:, 3:7], axis=1) - 1.0)) < 1e-14
 
 
-@settings(**{**SETTINGS, "max_examples": 40})
+@settings(**{**SETTINGS, "max_examples": _EXAMPLES or 40})
 @given(args=scene_args, split=st.floats(0.2, 0.8))
 def test_ba_append_order_does_not_change_the_result(hip, sfm, args, split):
     """The same scene built in one piece and grown by an append (new points with their observations) iterates to the
@@ -85,7 +92,7 @@ def _projections(sfm, sc, cams):
     return projs
 
 
-@settings(**{**SETTINGS, "max_examples": 30})
+@settings(**{**SETTINGS, "max_examples": (_EXAMPLES // 4) or 30})
 @given(n_views=st.integers(2, 9), n_pts=st.integers(1, 700), seed=st.integers(0, 10_000), iters=st.integers(0, 25),
        lam=st.sampled_from([0.1, 0.5, 5.0]))
 def test_nonlinear_triangulation_random_matches_oracle(hip, oracle, sfm, n_views, n_pts, seed, iters, lam):
@@ -102,7 +109,7 @@ def test_nonlinear_triangulation_random_matches_oracle(hip, oracle, sfm, n_views
     assert rel(got, want) < TOL
 
 
-@settings(**{**SETTINGS, "max_examples": 30})
+@settings(**{**SETTINGS, "max_examples": (_EXAMPLES // 4) or 30})
 @given(n_pts=st.integers(6, 500), seed=st.integers(0, 10_000), iters=st.integers(1, 30), quirks=st.sampled_from([0, 1, 2, 3]))
 def test_nonlinear_pnp_random_matches_oracle(hip, oracle, sfm, n_pts, seed, iters, quirks):
     """campose:308-459 on random point counts / iteration counts / quirk flags: one view of a two-view scene, started
@@ -118,7 +125,7 @@ def test_nonlinear_pnp_random_matches_oracle(hip, oracle, sfm, n_pts, seed, iter
     assert rel(r, ro) < TOL and rel(c, co) < TOL
 
 
-@settings(**{**SETTINGS, "max_examples": 30})
+@settings(**{**SETTINGS, "max_examples": (_EXAMPLES // 4) or 30})
 @given(args=scene_args, iters=st.integers(2, 5), mode=st.sampled_from(["auto", "pairs", "mfma"]))
 def test_ba_deterministic_graph_and_eager_agree_bitwise(hip, sfm, args, iters, mode):
     """SFM_OPT_DETERMINISTIC: two runs, and a hipGraph replay of the same run, give identical bits on random scenes."""
