@@ -226,22 +226,32 @@ __device__ __forceinline__ double rcp_nr(double d) {
 // cam_prepare (sfm_math.h) for serial sections of a kernel: the same predicate and the same formulas with the divisions and
 // the square root replaced by v_rcp_f64 / v_rsq_f64 + one third-order step (1e-16 relative; ~10 instructions each instead
 // of ~40).  verify_rotation's one-sided 1e-8 thresholds are ten orders of magnitude above that difference.
+//
+// VERIFY = false leaves out verify_rotation's determinant and inverse (≈70 of the ≈130 instructions) and is only for a
+// quaternion that the caller has JUST normalised with rsqrt_nr: |q|^2 = 1 + e with |e| of a few 1e-16, and R(q) = Q + e (Q - I)
+// for an orthonormal Q, so det R - 1 and inv(R) - R^T are of the order of e, eight orders of magnitude below the 1e-8
+// the predicate tests -- it cannot fire.  A NaN / Inf quaternion does not reach it either way: every comparison of the
+// predicate is written so that NaN passes (as the reference's `>` comparisons do), and such a camera ends in
+// SFM_E_QW_ZERO below in both forms.
+template <bool VERIFY = true>
 __device__ __forceinline__ int cam_prepare_dev(const double* cam7, CamPrep* out) {
   out->C[0] = cam7[0]; out->C[1] = cam7[1]; out->C[2] = cam7[2];
   quat_to_rot(cam7 + 3, out->R);
   const double* R = out->R;
   for (int j = 0; j < 3; ++j) out->t[j] = R[0 + j] * -cam7[0] + R[3 + j] * -cam7[1] + R[6 + j] * -cam7[2];
-  const double d = det3(R);
-  bool ok = !(d - 1 >= kRotTol);
-  const double id = rcp_nr(d);
-  const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
-                         (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
-                         (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+  if (VERIFY) {
+    const double d = det3(R);
+    bool ok = !(d - 1 >= kRotTol);
+    const double id = rcp_nr(d);
+    const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                           (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                           (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) ok = ok && !(inv[3 * i + j] - R[3 * j + i] > kRotTol);
-  if (!ok) return SFM_E_BAD_ROTATION;
+      for (int j = 0; j < 3; ++j) ok = ok && !(inv[3 * i + j] - R[3 * j + i] > kRotTol);
+    if (!ok) return SFM_E_BAD_ROTATION;
+  }
   const double tr1 = 1 + R[0] + R[4] + R[8];
   if (tr1 < 0) return SFM_E_SQRT_DOMAIN;
   const double qw = tr1 > 0 ? 0.5 * tr1 * rsqrt_nr(tr1) : 0.0;

@@ -762,8 +762,9 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     const double inq = rsqrt_nr(params[3] * params[3] + params[4] * params[4] + params[5] * params[5] + params[6] * params[6]);
 #pragma unroll
     for (int i = 3; i < 7; ++i) params[i] *= inq;
-    // campose:422: R = R(q) validated; the next Jacobian re-derives q from R (campose:464)
-    st = cam_prepare_dev(params, &c);
+    // campose:422: R = R(q) validated -- for the quaternion normalised two lines up the determinant / inverse test cannot
+    // fire (cam_prepare_dev<false>, sfm_common.h); the next Jacobian re-derives q from R (campose:464)
+    st = cam_prepare_dev<false>(params, &c);
   }
   if (tid == 0) {
     if (iters <= 0 && st == SFM_OK) st = cam_prepare_dev(params, &c);      // no iteration: the reference still returns R(q0) (campose:458)
