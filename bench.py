@@ -5,6 +5,8 @@
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (N > 1, no launcher environment: starts the line above as a CHILD process itself,
+                                         before torch is imported or a GPU touched, and relays rank 0's line + exit code)
 
 A "step" is one damped Gauss-Newton iteration (ba_processor.py:297-406): linearise all
 observations, form the Schur-reduced camera system, solve it, update cameras, back-substitute
@@ -13,7 +15,9 @@ points.  Inputs are resident in HBM before the timed region.
   --config C3 (default, the headline): for N > 1 the scene is WEAK-scaled: 50 cameras x (20 000 N) points,
       each rank owns a contiguous ~20 000-point shard and one RCCL all-reduce of [S | rhs] per iteration
       joins them; `value` counts 20 000-point shard-iterations per second over all ranks (= N x global
-      iterations/s).
+      iterations/s).  For N > 1 the line ALSO carries `strong_scaled`: the metric's own fixed 50 x 20 000 scene split
+      over the ranks by sharding.shard_bounds, its own timed regions, global iterations/s (`--scaling strong` swaps
+      the two; `--single-scaling` times only one).  `hbm.per_rank_algorithmic_frac_of_peak` at every N.
   --config C4 (BASELINE config 4): STRONG-scaled: the 200-camera x 100 000-point scene is fixed, its
       points are split over the N ranks by sharding.shard_bounds (balanced by camera pairs); `value` is
       global LM iterations per second of that one scene, "scaling": "strong".
@@ -28,7 +32,12 @@ points.  Inputs are resident in HBM before the timed region.
 Timing: W warm-up steps (every kernel class bracketed: which one dominates), the event-bracket calibration, then an
 untimed PRE-ROLL of the same steps until ~30 ms of GPU work have passed (`preroll_steps` in the line; `--no-preroll`
 skips it): a step is 0.3 ms, so after the host-side calibration the clocks are down and K = 20 steps would be over before
-they are back up.  Then barrier + synchronize, EXACTLY K steps, synchronize + barrier, MAX over ranks.
+they are back up.  Then R (= --repeats, 5) timed regions back to back, each barrier + synchronize, EXACTLY K steps,
+synchronize + barrier, MAX over ranks; `value` / `ms_per_step` are the MEDIAN region, `value_runs` / `ms_per_step_runs`
+list all of them (the error bar of a 5.6 ms measurement).
+N > 1: the replicated solves must leave every rank with the same cameras; `max_camera_deviation_across_ranks` records it.
+A non-zero deviation is not a lost run: the measurement is repeated with reduce(dst=0) + broadcast in place of the
+all-reduce (`--collective reduce_broadcast` forces that form) and `replica_drift` keeps the first figures.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, hipEvent-timed inside the timed
 region) and `cpu_baseline` (the NumPy oracle on the host cores, N = 1 only).
@@ -275,17 +284,43 @@ def finish(ctx, out):
 # ================================================================================================================
 # BA (C3 / C4)
 # ================================================================================================================
-def run_ba(args, ctx):
+def make_all_reduce(ctx, mode):
+    """The per-iteration exchange of the packed [S | rhs] buffer.
+    "allreduce": one RCCL all-reduce (SUM, f64), in place.  "reduce_broadcast": reduce to rank 0, then broadcast -- every rank
+    then holds rank 0's bytes whatever algorithm RCCL picked, so the replicated solves cannot drift apart; it is the repair
+    the bench falls back to (and prices) when an all-reduce turns out not to be bit-identical across ranks."""
+    dist = ctx.dist
+    if not ctx.use_dist:
+        return None
+    if ctx.rehearsal:                      # gloo through host memory where RCCL sits
+        def op(t):
+            host = t.cpu()
+            if mode == "reduce_broadcast":
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                dist.broadcast(host, src=0)
+            else:
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        return op
+    if mode == "reduce_broadcast":
+        def op(t):
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            dist.broadcast(t, src=0)
+        return op
+    return lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def ba_measure(args, ctx, sfm, strong, full, collective):
+    """One BA workload on this process group: scene, shard, (parity leg), warm-up, pre-roll, R timed regions of EXACTLY
+    K steps each.  `strong`: the scene is the config's own (points split over the ranks); otherwise every rank owns
+    `pts` points of an N-times larger scene.  `full`: also the parity leg, the kernel breakdown and the roofline of the
+    dominant kernel.  Returns (out dict, leftovers for the CPU legs)."""
     torch, dist = ctx.torch, ctx.dist
-    sfm = importlib.import_module("structure-from-motion_amd")
     native = sfm.native
     world, rank, device, use_dist, rehearsal = ctx.world, ctx.rank, ctx.device, ctx.use_dist, ctx.rehearsal
-
-    # ---- workload: C3 weak-scaled (points per rank fixed), C4 strong-scaled (scene fixed) --------------
     cfg = dict(sfm.scenes.CONFIGS[args.config])
-    strong = args.config == "C4" and args.pts is None
     pts_per_rank = args.pts or cfg["n_pts"]
-    total_pts = cfg["n_pts"] if strong else pts_per_rank * world
+    total_pts = (args.pts or cfg["n_pts"]) if strong else pts_per_rank * world
     scene = sfm.scenes.make_scene(cfg["n_cams"], total_pts, cfg["visibility"], seed=0)
     uvn = sfm.geometry.normalise_pixels(scene.uv_pix, scene.intrinsic)
     bounds = sfm.sharding.shard_bounds(scene.pt_ptr, world)
@@ -296,13 +331,7 @@ def run_ba(args, ctx):
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
     if args.debug:
         engine.prob.set_option(native.OPT_DEBUG, args.debug)
-    all_reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_dist else None
-    if use_dist and rehearsal:
-        def all_reduce(t):
-            host = t.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            t.copy_(host)
-    ba = sfm.sharding.ShardedBa(engine, all_reduce, world)
+    ba = sfm.sharding.ShardedBa(engine, make_all_reduce(ctx, collective), world)
     sync = ctx.sync
 
     def gather_state():
@@ -313,12 +342,14 @@ def run_ba(args, ctx):
         dist.all_gather_object(parts, pts_loc)
         return cams, np.hstack(parts)
 
-    # ---- parity leg: the reference's default 3 iterations from the initial estimate -----------
-    engine.set_state(scene.cams_init, pts_l)
-    ba.iterate(LAMBDA, 3)
-    cams3, pts3 = gather_state()
-    rmse_init = sfm.scenes.reprojection_rmse(scene.cams_init, scene.pts_init, scene)
-    rmse_gpu3 = sfm.scenes.reprojection_rmse(cams3, pts3, scene)
+    rmse_init = rmse_gpu3 = None
+    cams3 = pts3 = None
+    if full:      # parity leg: the reference's default 3 iterations from the initial estimate
+        engine.set_state(scene.cams_init, pts_l)
+        ba.iterate(LAMBDA, 3)
+        cams3, pts3 = gather_state()
+        rmse_init = sfm.scenes.reprojection_rmse(scene.cams_init, scene.pts_init, scene)
+        rmse_gpu3 = sfm.scenes.reprojection_rmse(cams3, pts3, scene)
 
     # ---- warmup with every kernel class bracketed: find the dominant kernel --------------------
     engine.set_state(scene.cams_init, pts_l)
@@ -334,7 +365,7 @@ def run_ba(args, ctx):
     dominant = max((n for n in breakdown if n != "prep"), key=lambda n: breakdown[n])
     dom_id = native.KERNEL_NAMES.index(dominant)
 
-    # ---- timed region: exactly K steps, only the dominant kernel bracketed by hipEvents ----------
+    # ---- timed regions: exactly K steps each, only the dominant kernel bracketed by hipEvents ----------
     # (sampled: a hipEvent pair puts two ~6 us bubbles into the stream, 3.6 % of a C3 iteration if every launch is bracketed)
     engine.prob.set_option(native.OPT_TIMING, 1 << dom_id)
     stride = args.timing_stride if args.timing_stride > 0 else max(1, min(10, args.steps // 5))
@@ -342,19 +373,24 @@ def run_ba(args, ctx):
     # The W warm-up steps above are followed by host-side calibration, so the GPU is idle and its clocks are down when the
     # timed region would start; at 0.28 ms a step, K = 20 steps are over before they are back up (measured: 3 408 it/s with
     # W = 3 against 3 581 with W = 50, the dense product at 138.7 vs 126.3 us).  An untimed pre-roll of the same steps runs
-    # until ~30 ms of GPU work have passed, immediately before the barrier that opens the timed region; its length is in
-    # the line ("preroll_steps").
+    # until ~30 ms of GPU work have passed, immediately before the barrier that opens the first timed region; its length
+    # is in the line ("preroll_steps").
     est_step_ms = ctx.max_over_ranks(sum(v for k, v in breakdown.items() if k != "prep"))
     preroll = 0 if args.no_preroll else int(max(0, min(400, PREROLL_MS / max(est_step_ms, 1e-3))))
     if preroll:
         ba.iterate(LAMBDA, preroll)
         sync()
     engine.prob.reset_timing()
-    sync()
-    t0 = time.perf_counter()
-    ba.iterate(LAMBDA, args.steps)
-    sync()
-    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    # R back-to-back regions of EXACTLY K steps (the 5.6 ms headline gets an error bar); every region is
+    # barrier + synchronize | K steps | synchronize + barrier, MAX over ranks; `value` is the median region
+    elapsed_runs = []
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        ba.iterate(LAMBDA, args.steps)
+        sync()
+        elapsed_runs.append(ctx.max_over_ranks(time.perf_counter() - t0))
+    elapsed = float(np.median(elapsed_runs))
     dom_ms, dom_n = engine.prob.kernel_time(dom_id)
     bracket_ms = dom_ms / max(1, dom_n)
     # solve = nbk + 1 launches inside one bracket: the bracket's own overhead is paid once
@@ -362,6 +398,62 @@ def run_ba(args, ctx):
     cams_end, pts_end = gather_state()
     rmse_end = sfm.scenes.reprojection_rmse(cams_end, pts_end, scene)
 
+    scale = 1 if strong else world
+    out = {
+        "metric": "BA LM-iterations/sec + final reprojection RMSE, 50 cams x 20k pts",
+        "value": scale * args.steps / elapsed,
+        "unit": ("LM-iterations/s of the one %dcam x %dk-pt scene (points split over the ranks)" % (scene.n_cams, scene.n_pts // 1000) if strong else
+                 "LM-iterations/s (%dcam x %dk-pt shard-iterations, all ranks)" % (scene.n_cams, pts_per_rank // 1000)),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "repeats": len(elapsed_runs),
+        "value_runs": [scale * args.steps / e for e in elapsed_runs],
+        "ms_per_step_runs": [e / args.steps * 1e3 for e in elapsed_runs],
+        "value_note": "`value` / `ms_per_step` = the MEDIAN of %d back-to-back timed regions of exactly %d steps each (one pre-roll before the first)" % (len(elapsed_runs), args.steps),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
+        "config": {"workload": ("%s: %d cams x %d pts in total @ %.0f%% visibility, strong-scaled: %d..%d pts per rank, lambda=5, Schur BA" % (
+                                    args.config, scene.n_cams, scene.n_pts, 100 * cfg["visibility"],
+                                    int(np.min(np.diff(bounds))), int(np.max(np.diff(bounds))))) if strong else
+                               ("%s: %d cams x %d pts/rank @ %.0f%% visibility, lambda=5, Schur BA" % (
+                                    args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"])),
+            "observations_per_rank": int(cam_l.shape[0]), "points_total": int(scene.n_pts),
+            "parallelism": "points sharded x%d, cameras replicated, %s of [S|rhs] per iteration" % (world, collective) if world > 1 else "single GPU",
+            "collective_backend": ctx.backend,
+            "schur": args.schur, **({"debug_bits": args.debug} if args.debug else {})},
+        "rmse_px": {"initial": rmse_init, "after_3_iterations": rmse_gpu3, "after_timed_run": rmse_end},
+    }
+    # whole-iteration HBM figures per rank (north_star: achieved HBM-bandwidth fraction at every N): algorithmic
+    # bytes of one iteration (20 M + 52 N + 112 V) over the measured time of one iteration
+    iter_s = elapsed / args.steps
+    alg_bytes = 20 * int(cam_l.shape[0]) + 52 * (int(ptr_l.shape[0]) - 1) + 112 * scene.n_cams
+    out["hbm"] = {"algorithmic_bytes_per_iteration": alg_bytes, "algorithmic_GBps": alg_bytes / iter_s / 1e9,
+                  "algorithmic_frac_of_peak": alg_bytes / iter_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
+                  "measured_bytes_per_iteration": None}
+    if use_dist and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, alg_bytes)
+        out["hbm"]["per_rank_algorithmic_bytes_per_iteration"] = per_rank
+        out["hbm"]["per_rank_algorithmic_frac_of_peak"] = [b / iter_s / 1e9 / HBM_PEAK_GBS for b in per_rank]
+        out["hbm"]["whole_job_algorithmic_GBps"] = sum(per_rank) / iter_s / 1e9
+
+    # ---- N > 1: do the ranks hold bit-identical cameras after the replicated solves?  Recorded, never fatal ------------
+    if use_dist and world > 1:
+        cams_dev = torch.from_numpy(np.ascontiguousarray(cams_end)).to(ctx.coll_device)
+        ref = cams_dev.clone()
+        dist.broadcast(ref, src=0)
+        dev = (cams_dev - ref).abs().max().reshape(1)
+        dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+        out["max_camera_deviation_across_ranks"] = float(dev.item())
+
+    extra = Holder()
+    extra.scene, extra.uvn, extra.engine, extra.cams3, extra.pts3, extra.rmse_gpu3 = scene, uvn, engine, cams3, pts3, rmse_gpu3
+    if not full:
+        engine.close()
+        return out, extra
+
+    out["kernel_ms"] = breakdown
+    out["kernel_ms_note"] = "hipEvent brackets of the warm-up, every class bracketed, each INCLUDING the bracket's own %.1f us" % (event_overhead_ms * 1e3)
     costs = algorithmic_costs(scene.n_cams, ptr_l, int(cam_l.shape[0]))
     c = costs[dominant]
     if c["bound"] == "mfma":
@@ -383,7 +475,7 @@ def run_ba(args, ctx):
     roofline["avg_launch_ms"] = dom_avg_ms
     roofline["event_bracket_ms"] = bracket_ms
     roofline["event_overhead_ms"] = event_overhead_ms
-    roofline["timing_note"] = ("avg_launch_ms = hipEvent bracket of this kernel class (every %d-th launch of the timed region, %d samples) minus the "
+    roofline["timing_note"] = ("avg_launch_ms = hipEvent bracket of this kernel class (every %d-th launch of the timed regions, %d samples) minus the "
                                "bracket an empty kernel reads on the same stream (sfm_ba_event_overhead, less the %.1f us the empty kernel itself takes); "
                                "rocprofv3's average for the same command is committed under profiles/" % (stride, dom_n, EMPTY_KERNEL_MS * 1e3))
     roofline["launches"] = dom_n
@@ -407,40 +499,6 @@ def run_ba(args, ctx):
         if per:
             roofline["traffic"] = sum(per.values())
             roofline["traffic_unit"] = "HBM bytes per iteration of this kernel class (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json[%r])" % workload_key
-
-    out = {
-        "metric": "BA LM-iterations/sec + final reprojection RMSE, 50 cams x 20k pts",
-        "value": (1 if strong else world) * args.steps / elapsed,
-        "unit": ("LM-iterations/s of the one 200cam x 100k-pt scene (points split over the ranks)" if strong else
-                 "LM-iterations/s (50cam x 20k-pt shard-iterations, all ranks)"),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU, gloo): not a measurement",
-        "config": {"workload": ("%s: %d cams x %d pts in total @ %.0f%% visibility, strong-scaled: %d..%d pts per rank, lambda=5, Schur BA" % (
-                                    args.config, scene.n_cams, scene.n_pts, 100 * cfg["visibility"],
-                                    int(np.min(np.diff(bounds))), int(np.max(np.diff(bounds))))) if strong else
-                               ("%s: %d cams x %d pts/rank @ %.0f%% visibility, lambda=5, Schur BA" % (
-                                    args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"])),
-            "observations_per_rank": int(cam_l.shape[0]), "points_total": int(scene.n_pts),
-            "parallelism": "points sharded x%d, cameras replicated, all-reduce [S|rhs]" % world if world > 1 else "single GPU",
-            "collective_backend": ctx.backend,
-            "schur": args.schur, **({"debug_bits": args.debug} if args.debug else {})},
-        "rmse_px": {"initial": rmse_init, "after_3_iterations": rmse_gpu3, "after_timed_run": rmse_end},
-        "kernel_ms": breakdown,
-        "kernel_ms_note": "hipEvent brackets of the warm-up, every class bracketed, each INCLUDING the bracket's own %.1f us" % (event_overhead_ms * 1e3),
-        "roofline": roofline,
-    }
-    # whole-iteration HBM figures per rank (north_star: achieved HBM-bandwidth fraction at every N): algorithmic
-    # bytes of one iteration (20 M + 52 N + 112 V) and, when profiles/traffic.json matches
-    # this configuration's kernels, the bytes rocprofv3's PMC passes measured per iteration (materialised
-    # intermediates such as the dense Z included), both over the measured time of one iteration
-    iter_s = elapsed / args.steps
-    alg_bytes = 20 * int(cam_l.shape[0]) + 52 * (int(ptr_l.shape[0]) - 1) + 112 * scene.n_cams
-    out["hbm"] = {"algorithmic_bytes_per_iteration": alg_bytes, "algorithmic_GBps": alg_bytes / iter_s / 1e9,
-                  "algorithmic_frac_of_peak": alg_bytes / iter_s / 1e9 / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS,
-                  "measured_bytes_per_iteration": None}
-    if traffic_rec:
         have = {k: n for k, n in launches.items() if isinstance(traffic_rec.get(k), (int, float))}
         meas = sum(traffic_rec[k] * n for k, n in have.items())
         out["hbm"].update({"measured_bytes_per_iteration": meas, "measured_GBps": meas / iter_s / 1e9,
@@ -449,19 +507,40 @@ def run_ba(args, ctx):
                            "measured_source": "profiles/traffic.json[%r] (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per kernel; a committed "
                                               "record of an earlier run of this workload, not measured in this run; only the kernels a "
                                               "steady-state iteration launches, times their launches per iteration)" % workload_key})
+    out["roofline"] = roofline
+    return out, extra
 
-    # ---- N > 1: every rank must hold bit-identical cameras after the redundant solves -----------------
-    if use_dist and world > 1:
-        cams_dev = torch.from_numpy(np.ascontiguousarray(cams_end)).to(ctx.coll_device)
-        ref = cams_dev.clone()
-        dist.broadcast(ref, src=0)
-        dev = (cams_dev - ref).abs().max().reshape(1)
-        dist.all_reduce(dev, op=dist.ReduceOp.MAX)
-        out["max_camera_deviation_across_ranks"] = float(dev.item())
-        if float(dev.item()) != 0.0:
-            if rank == 0:
-                print(json.dumps(out))
-            raise SystemExit("ranks disagree on the cameras after the replicated reduced solve: max |cams - cams(rank 0)| = %g" % float(dev.item()))
+
+def run_ba(args, ctx):
+    sfm = importlib.import_module("structure-from-motion_amd")
+    native = sfm.native
+    world, rank = ctx.world, ctx.rank
+    # C4 is the fixed 200 x 100k scene (strong); C3 weak-scales by default (every rank its own 20k-point shard) and, for N > 1,
+    # ALSO times the metric's own fixed 50 x 20k scene split over the ranks (`strong_scaled` in the line); --scaling strong
+    # makes that one `value`
+    c4_fixed = args.config == "C4" and args.pts is None
+    primary_strong = c4_fixed or args.scaling == "strong"
+    collective = args.collective
+    out, extra = ba_measure(args, ctx, sfm, primary_strong, True, collective)
+    if ctx.use_dist and world > 1 and out.get("max_camera_deviation_across_ranks", 0.0) != 0.0 and collective == "allreduce":
+        # replicas drifted: the all-reduce did not hand every rank the same bytes.  Not a lost run: record it, repeat the
+        # measurement with the reduce + broadcast exchange (identical bytes by construction) and report THAT as `value`
+        drift = {"max_camera_deviation_across_ranks": out["max_camera_deviation_across_ranks"], "value_with_drift": out["value"],
+                 "ms_per_step_with_drift": out["ms_per_step"],
+                 "note": "torch.distributed.all_reduce left the ranks with different [S | rhs] bits; re-measured with reduce(dst=0) + broadcast"}
+        extra.engine.close()
+        collective = "reduce_broadcast"
+        out, extra = ba_measure(args, ctx, sfm, primary_strong, True, collective)
+        out["replica_drift"] = drift
+    if ctx.use_dist and world > 1 and args.config == "C3" and not args.single_scaling:
+        other, _extra2 = ba_measure(args, ctx, sfm, not primary_strong, False, collective)
+        key = "weak_scaled" if primary_strong else "strong_scaled"
+        out[key] = {k: other[k] for k in ("value", "unit", "ms_per_step", "value_runs", "ms_per_step_runs", "scaling", "hbm", "rmse_px") if k in other}
+        out[key]["workload"] = other["config"]["workload"]
+        if "max_camera_deviation_across_ranks" in other:
+            out[key]["max_camera_deviation_across_ranks"] = other["max_camera_deviation_across_ranks"]
+    scene, uvn, engine = extra.scene, extra.uvn, extra.engine
+    cams3, pts3, rmse_gpu3 = extra.cams3, extra.pts3, extra.rmse_gpu3
 
     # ---- CPU baseline (rank 0, N = 1): the NumPy block-sparse oracle on the same scene --------------------------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -872,11 +951,65 @@ def run_c5(args, ctx):
     finish(ctx, out)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (what the driver's SCALE run may issue): this
+    process -- which has not imported torch and never touches a GPU -- starts the N ranks as CHILD processes
+    (`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`, rendezvous on 127.0.0.1), lets
+    rank 0's single JSON line through on stdout and returns the launcher's exit code.  Never exec: a parent that had
+    initialised the GPU must not replace itself, and this way the rule cannot be broken by a later edit either."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("SFM_BENCH_TRACE_LAUNCH", "0") == "1":
+        print("bench.py launcher: torch imported in the parent: %s; child command: %s" % ("torch" in sys.modules, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env)          # stdout / stderr inherited: the ranks' output is this process's output
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
+def dry_rank(args):
+    """SFM_BENCH_DRY=1: the rank-side control flow without a GPU (CPU tests): rendezvous over gloo, one all-reduce,
+    rank 0 prints a marked JSON line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t.item()), "config": {"workload": args.config},
+                          "data": "none: SFM_BENCH_DRY=1 (launcher / rendezvous check, no GPU work)"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="back-to-back timed regions of exactly --steps steps each; `value` is their median (BA configs)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="C3 with N > 1: which figure is `value` (auto = weak: 20 000 points per rank; strong = the fixed 50 x 20k scene split "
+                         "over the ranks); the other one is timed as well and reported next to it")
+    ap.add_argument("--single-scaling", action="store_true", help="C3 with N > 1: time only the figure --scaling names")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_broadcast"],
+                    help="the per-iteration exchange of [S | rhs]; reduce_broadcast is the repair the bench falls back to by itself when "
+                         "the ranks' cameras drift apart under allreduce")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "TRI", "PNP", "C5"])
     ap.add_argument("--pts", type=int, default=None, help="override points per rank / per view (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -893,6 +1026,13 @@ def main():
         leg = cpu_leg(args.cpu_leg, args.config if args.config in ("C3", "C4") else "C3", args.cpu_iters, args.cpu_repeats, args.pts)
         leg.pop("state3", None)
         print(json.dumps(leg))
+        return
+
+    # N > 1 without a launcher's environment: become the parent of N ranks (before torch is imported, before any GPU call)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("SFM_BENCH_DRY", "0") == "1":
+        dry_rank(args)
         return
 
     ctx = setup_dist(args)

@@ -137,6 +137,12 @@ class ObservationTracker:
             if cand.size:
                 if cand[0] == 0:                                     # key index 0 is special (Q3)
                     return None
+                # key 0 of this view already maps to one of the new ids: alone it was invisible (Q3: np.any tests the index
+                # VALUES), with a second key the point becomes visible THROUGH KEY 0 (key_idx[0][0], key_tracker.py:198-204),
+                # not through the new key -- rebuild rather than emit the wrong pixel
+                r0 = int(row[0]) if row.shape[0] else -1
+                if 0 <= r0 < n_pts and np.any(ids == r0):
+                    return None
                 seen = self.seen[c]
                 old_ids = ids[ids < seen.shape[0]]
                 if np.any(seen[old_ids]) or np.unique(ids).shape[0] != ids.shape[0]:

@@ -149,6 +149,11 @@ class HipShardEngine:
     def flush(self):
         self.prob.flush()
 
+    def iterate_local(self, lam, iters, quirks=native.QUIRKS_REFERENCE):
+        """``iters`` complete iterations with NO exchange step (one rank owns every point): one C-ABI call
+        (``sfm_ba_iterate``), the path the drop-in classes take."""
+        self.prob.iterate(lam, iters, quirks)
+
     def get_state(self):
         return self.prob.get_state()
 
@@ -168,6 +173,10 @@ class ShardedBa:
 
     def iterate(self, lam, iters, quirks=native.QUIRKS_REFERENCE):
         with self.engine.stream_context():
+            local = getattr(self.engine, "iterate_local", None)
+            if self.all_reduce is None and local is not None:      # nothing to exchange: the whole loop is one library call
+                local(lam, iters, quirks)
+                return
             for _ in range(iters):
                 buf = self.engine.linearize_reduce(lam, quirks)
                 if self.all_reduce is not None:

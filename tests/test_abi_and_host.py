@@ -175,6 +175,40 @@ def test_observation_tracker_equals_full_rebuild(sfm):
     assert np.array_equal(obs.KeyCache().gather_normalised(views, cam_idx, key_idx), obs.gather_normalised_keys(views, cam_idx, key_idx))
 
 
+def test_observation_tracker_key_zero_then_second_key(sfm):
+    """key 0 of a view maps to point X -- alone it is invisible (Q3: np.any tests the index VALUES,
+    key_tracker.py:198-204) -- and after a reset a free key k > 0 of the same view is set to X.  The reference (and
+    build_observations) now report the point through KEY 0 (key_idx[0][0]); the diff must not emit (cam, X, k)."""
+    obs = sfm.observations
+    row = np.full(8, -1, dtype=np.int64)
+    row[0] = 3
+    row[2] = 1
+    tr = obs.ObservationTracker()
+    _ptr, cam, pt, key = tr.reset([row], 5)
+    assert list(zip(cam.tolist(), pt.tolist(), key.tolist())) == [(0, 1, 2)]          # key 0 -> point 3 is invisible
+    grown = row.copy()
+    grown[5] = 3
+    want = obs.build_observations([grown], 5)
+    assert sorted(zip(want[1].tolist(), want[2].tolist(), want[3].tolist())) == [(0, 1, 2), (0, 3, 0)]
+    got = tr.diff([grown], 5)
+    assert got is None                                                                # -> the caller rebuilds
+    _ptr, cam, pt, key = tr.reset([grown], 5)
+    assert sorted(zip(cam.tolist(), pt.tolist(), key.tolist())) == [(0, 1, 2), (0, 3, 0)]
+    # the same with an id that only becomes a point when the point count grows (key 0 is a late id: also a rebuild),
+    # and the harmless neighbour: a second key for a point key 0 does NOT map to is plain growth
+    row2 = np.full(8, -1, dtype=np.int64)
+    row2[0] = 6
+    tr2 = obs.ObservationTracker()
+    tr2.reset([row2], 5)
+    g2 = row2.copy(); g2[4] = 6
+    assert tr2.diff([g2], 7) is None
+    tr3 = obs.ObservationTracker()
+    tr3.reset([row], 5)
+    g3 = row.copy(); g3[6] = 4
+    got3 = tr3.diff([g3], 5)
+    assert got3 is not None and list(zip(got3[0].tolist(), got3[1].tolist(), got3[2].tolist())) == [(0, 4, 6)]
+
+
 def test_header_is_plain_c_and_links_from_a_c_program(sfm, tmp_path):
     """include/sfm_hip.h is the drop-in boundary: it must compile as C (no C++ types, no torch types) and a plain C program
     must be able to link libsfm_hip.so and call it.  Without a GPU the calls that need one fail with SFM_E_NO_DEVICE and a

@@ -5,6 +5,10 @@
 n=${1:-2}
 export SFM_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 run() { port=$1; shift; python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" bench.py --gpus "$n" "$@"; }
+# round 4: a plain `python3 bench.py --gpus N` (no launcher: the parent spawns the ranks itself), the full-size C3 line with
+# its strong-scaled companion, and the reduce + broadcast exchange forced
+python3 bench.py --gpus "$n" --steps 5 --warmup 2 --repeats 3 &&
+python3 bench.py --gpus "$n" --steps 5 --warmup 2 --repeats 2 --pts 4000 --collective reduce_broadcast --scaling strong &&
 run 29533 --steps 5 --warmup 2 --pts 4000 &&
 run 29534 --steps 3 --warmup 1 --config C4 &&
 run 29535 --steps 5 --warmup 1 --config TRI --pts 200000 &&
