@@ -41,15 +41,21 @@ extern "C" {
 #define SFM_Q1_PNP_ROW_OVERLAP  1  /* campose_processor.py:404-405: rows stored at [pt:pt+2] */
 #define SFM_Q2_LOC_JAC_SIGN     2  /* campose_processor.py:802-804: sign of the v-row of d/dC */
 #define SFM_QUIRKS_REFERENCE    3
-/* Q13 (documented, NOT reproducible, therefore not a selectable bit): the six-point DLT of the linear PnP
- * (campose_processor.py:565-633) negates loc together with rot when det(rot) < 0 (campose:629-631).  rot and the
- * null vector it comes from flip sign together, loc = rot @ -cam_mat[:, 3] / s does not -- so whether that branch
+/* Q13 (not a selectable bit: it is not a property of the arithmetic but of the host's LAPACK): the six-point DLT of the
+ * linear PnP (campose_processor.py:565-633) negates loc together with rot when det(rot) < 0 (campose:629-631).  rot and
+ * the null vector it comes from flip sign together, loc = rot @ -cam_mat[:, 3] / s does not -- so whether that branch
  * is taken, and with it whether the returned centre is C or -C, depends on the arbitrary sign LAPACK gives the
  * last right-singular vector.  Measured on the reference's own PnP fixture (tests/golden/g5_pnp.npz, 300 seeded
- * hypotheses): the branch fires for about half of them and each of those scores <= 1 inlier in the reference.
- * The device returns the sign-invariant centre for every hypothesis: identical (R, C, inlier count) wherever the
- * reference did not take the branch, the correct pose where it did.  tests/test_gpu_linear_and_incremental.py
- * asserts exactly that, hypothesis by hypothesis. */
+ * hypotheses) and on the captured per-view chains (tests/golden/g10_incremental_*.npz): the branch fires for about half
+ * of the hypotheses, each of which then usually scores next to nothing -- so the reference's winner is the first
+ * best hypothesis AMONG THOSE ITS LAPACK DID NOT RUIN, typically not the first best hypothesis.
+ * The device returns the sign-invariant centre C for every hypothesis (sfm_pnp_linear_ransac: the sane RANSAC).
+ * Reproducing the reference needs the host's LAPACK, so it is split (round 4): sfm_pnp_ransac_evaluate returns every
+ * hypothesis' pose and its inlier counts under (R, C) AND under (R, -C); the Python drop-in asks NumPy -- the very
+ * library the reference would have asked -- for the branch decision of the few hypotheses that can win
+ * (structure-from-motion_amd/q13.py), picks the reference's winner and fetches its inlier mask with
+ * sfm_pnp_inlier_mask.  tests/test_gpu_linear_and_incremental.py asserts the per-hypothesis facts on the reference's
+ * fixture, tests/test_gpu_chain_golden.py the winners, inlier lists and RNG stream of whole per-view chains. */
 #define SFM_Q13_PNP_LOC_SIGN_UNDEFINED 0
 
 /* ---- Schur-product algorithm selection (sfm_ba_set_option SFM_OPT_SCHUR) ---------------------- */
@@ -191,6 +197,16 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix /*[3][n]*/, const double* 
                           int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
                           double R_out[9], double C_out[3], int* inlier_mask /*[n]*/, int* n_inliers,
                           int* best_hypothesis);
+
+/* The same hypotheses, for a caller that reproduces quirk Q13 (above): pose (R, C) of every six-point sample, its inlier
+ * count under (R, C) and under (R, -C) -- what the reference scores when its det(rot) < 0 branch fired (campose:629-631). */
+int sfm_pnp_ransac_evaluate(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
+                            int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
+                            double* R_out /*[n_hyp][9]*/, double* C_out /*[n_hyp][3]*/, int* counts /*[n_hyp]*/,
+                            int* counts_neg /*[n_hyp]*/);
+/* Inlier mask and count of ONE pose: pixel reprojection error of every point against `threshold` (campose:544-554). */
+int sfm_pnp_inlier_mask(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
+                        const double R[9], const double C[3], double threshold, int* inlier_mask /*[n]*/, int* n_inliers);
 
 /* Parity hook: every hypothesis of the RANSAC above -- pose and inlier count of each six-point sample
  * (campose_processor.py:524-560 loop body, 565-633). */

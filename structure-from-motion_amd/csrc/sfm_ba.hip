@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // THREADS = 64 (one wave per workgroup) is the deterministic variant: the camera accumulators in LDS then receive
 // their ds_add_f64 from a single instruction stream, in program order.
 template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED, int THREADS = 256>
-__global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   static_assert(!FUSED || LDS_MODE == 2, "the fused kernel keeps both camera sets in LDS");
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
@@ -238,17 +238,24 @@ __global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur,
       const double e0 = r[0] - (Jx[0] * h0 + Jx[1] * h1 + Jx[2] * h2);
       const double e1 = r[1] - (Jx[3] * h0 + Jx[4] * h1 + Jx[5] * h2);
       int k = 0;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
-        acc[28 + i] = Jp[i] * e0 + Jp[7 + i] * e1;
-      }
       if (ACC_LDS) {
+        // row by row, every row's products handed to the LDS atomics before the next row is formed: all 35 values at once
+        // kept 70 VGPRs live across the 35 ds_add_f64 (168 VGPRs, three waves per SIMD)
         double* a = lds_acc + (size_t)cam * 35;
 #pragma unroll
-        for (int q = 0; q < 35; ++q) atomicAdd(a + q, acc[q]);
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) { atomicAdd(a + k, Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]); ++k; }
+          atomicAdd(a + 28 + i, Jp[i] * e0 + Jp[7 + i] * e1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) { acc[k] = Jp[i] * Jp[j] + Jp[7 + i] * Jp[7 + j]; ++k; }
+          acc[28 + i] = Jp[i] * e0 + Jp[7 + i] * e1;
+        }
         k = 0;
         for (int i = 0; i < 7; ++i)
           for (int j = 0; j <= i; ++j) { atomicAdd(&S[red_index(7 * cam + i, 7 * cam + j)], acc[k]); ++k; }

@@ -584,7 +584,21 @@ __device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
 // cached points per thread; sixteen waves would cap the kernel at 128 VGPRs and spill).  More lanes shorten only the
 // linearisation: every wave pays the same 35-value reduction (~630 issue slots) and the same serial 7x7 solve, so at
 // 1000 points 256 threads x 4 points take 4.6 us per iteration against 5.5 us for 512 x 2 (profiles/r3/bench_pnp_*.json).
-template <int THREADS, int PNP_CACHE>
+// SPLIT (round 4, third size class): a view of more than kPnpSplitMin points is dealt to k = ceil(n / 1024) workgroups of the
+// 256-thread, register-resident form (workgroup = blockIdx.x % kmax of view blockIdx.x / kmax; slices of ceil(n / k) points).
+// Per iteration every workgroup stores the 35 sums of its slice, arrives at the view's device-scope counter, waits until
+// all k have arrived and adds the k partial vectors IN SLICE ORDER -- so every workgroup holds the same bits, carries out
+// the same serial part and no camera has to be published (one hand-over per iteration, ~2 us, instead of two).  The
+// partial vectors are double-buffered by iteration parity: a workgroup cannot be two arrivals ahead of a sibling.
+// Which kernel refines a view still depends on the view's own size only.
+struct PnpSplitWs {
+  double* xch;   // [n_views][2][kmax][35]
+  int* ctr;      // [n_views] arrivals (monotone over the iterations of one launch; cleared before it)
+  int kmax;
+};
+constexpr int kPnpSplitSlice = 1024;
+
+template <int THREADS, int PNP_CACHE, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
                                                                 const double* __restrict__ uv_pix,
                                                                 const double* __restrict__ X,
@@ -593,7 +607,8 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
                                                                 const double* __restrict__ C0, double lambda, int iters,
                                                                 int quirks, double* __restrict__ R_out,
                                                                 double* __restrict__ C_out, int* __restrict__ status,
-                                                                int stage_mode, int stage_cap, int n_lo, int n_hi) {
+                                                                int stage_mode, int stage_cap, int n_lo, int n_hi,
+                                                                PnpSplitWs ws = PnpSplitWs{nullptr, nullptr, 1}, int view0 = 0) {
   // Views too large for the register cache keep their points in LDS when they fit (stage_mode 1: X, Y, Z, W and the
   // normalised key, 48 bytes per point, SoA over stage_cap points; 2: the normalised key only, the point is re-read from
   // L2): the key normalisation -- two divisions per point -- is then done once, not in every iteration.
@@ -602,12 +617,20 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
   __shared__ double kinv[9];
   __shared__ double red[4 * WAVES][35];      // one partial per 16-lane row of every wave
   __shared__ double sums[35];
-  const int view = blockIdx.x;
+  const int view = view0 + (SPLIT ? (int)blockIdx.x / ws.kmax : (int)blockIdx.x);
+  const int slice = SPLIT ? (int)blockIdx.x % ws.kmax : 0;
   const int base = offsets[view];
   const int n = offsets[view + 1] - base;
   if (n < n_lo || n > n_hi) return;          // the other size class' launch refines this view (enqueue_pnp_nonlinear)
+  const int nslices = SPLIT ? (n + kPnpSplitSlice - 1) / kPnpSplitSlice : 1;
+  if (SPLIT && slice >= nslices) return;
+  const int per = SPLIT ? (n + nslices - 1) / nslices : n;
+  const int p_lo = slice * per;                          // this workgroup's points: [p_lo, p_lo + n_mine) of the view
+  const int n_mine = SPLIT ? max(0, min(n, p_lo + per) - p_lo) : n;
+  __shared__ int split_fail;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  if (SPLIT && tid == 0) split_fail = 0;
 
   if (tid == 0) {
     const double* K = Kmat + 9 * view;
@@ -642,14 +665,14 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     pt[4] = (kinv[0] * u + kinv[1] * v + kinv[2] * h) / m2;
     pt[5] = (kinv[3] * u + kinv[4] * v + kinv[5] * h) / m2;
   };
-  const bool cached = n <= THREADS * PNP_CACHE;
+  const bool cached = n_mine <= THREADS * PNP_CACHE;
   // (the 256-thread variant never stages: its branch-free loop is what views of up to 1 024 points run)
   const int staged = (THREADS > 256 && !cached && n <= stage_cap) ? stage_mode : 0;
   double pts[PNP_CACHE][6];
   if (cached) {
 #pragma unroll
     for (int cc = 0; cc < PNP_CACHE; ++cc)
-      if (tid + THREADS * cc < n) load_point(tid + THREADS * cc, pts[cc]);
+      if (tid + THREADS * cc < n_mine) load_point(p_lo + tid + THREADS * cc, pts[cc]);
   } else if (staged) {
     for (int p = tid; p < n; p += THREADS) {
       double pt[6];
@@ -712,7 +735,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     if (cached) {
 #pragma unroll
       for (int cc = 0; cc < PNP_CACHE; ++cc)
-        if (tid + THREADS * cc < n) accumulate(pts[cc], tid + THREADS * cc);
+        if (tid + THREADS * cc < n_mine) accumulate(pts[cc], p_lo + tid + THREADS * cc);
     } else {
       for (int p = tid; p < n; p += blockDim.x) {
         double pt[6];
@@ -745,7 +768,33 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
       double t = red[0][tid];
 #pragma unroll
       for (int w = 1; w < 4 * WAVES; ++w) t += red[w][tid];
-      sums[tid] = t;
+      if (SPLIT) ws.xch[(((size_t)view * 2 + (it & 1)) * ws.kmax + slice) * 35 + tid] = t;
+      else sums[tid] = t;
+    }
+    if (SPLIT) {
+      // hand-over: wave 0 stored the slice's sums -> agent-scope release -> arrive -> wait for all slices of the view ->
+      // barrier -> agent-scope acquire -> the partial vectors of all slices, added in slice order
+      if (wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid == 0) {
+          __hip_atomic_fetch_add(ws.ctr + view, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          const int want = nslices * (it + 1);
+          const unsigned long long t0 = wall_clock64();
+          while (__hip_atomic_load(ws.ctr + view, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (wall_clock64() - t0 > 200000000ull) { split_fail = 1; break; }      // 2 s: a sibling never ran (never seen)
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (split_fail) { st = SFM_E_HIP; break; }
+      if (tid < 35) {
+        const double* part = ws.xch + (((size_t)view * 2 + (it & 1)) * ws.kmax) * 35 + tid;
+        double t = part[0];
+        for (int g = 1; g < nslices; ++g) t += part[(size_t)g * 35];
+        sums[tid] = t;
+      }
     }
     __syncthreads();
     double a[28], b[7];
@@ -766,7 +815,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
     // fire (cam_prepare_dev<false>, sfm_common.h); the next Jacobian re-derives q from R (campose:464)
     st = cam_prepare_dev<false>(params, &c);
   }
-  if (tid == 0) {
+  if (tid == 0 && slice == 0) {
     if (iters <= 0 && st == SFM_OK) st = cam_prepare_dev(params, &c);      // no iteration: the reference still returns R(q0) (campose:458)
     for (int k = 0; k < 9; ++k) R_out[9 * view + k] = c.R[k];
     for (int k = 0; k < 3; ++k) C_out[3 * view + k] = params[k];
@@ -795,7 +844,8 @@ __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, con
                                                            const double* __restrict__ Kmat,
                                                            double* __restrict__ R_out /*[n_hyp][9]*/,
                                                            double* __restrict__ C_out /*[n_hyp][3]*/,
-                                                           double* __restrict__ proj_out /*[n_hyp][12]*/) {
+                                                           double* __restrict__ proj_out /*[n_hyp][12]*/,
+                                                           double* __restrict__ proj_neg_out /*[n_hyp][12] or null: K [R^T | R^T C], the pose (R, -C)*/) {
   const int h = blockIdx.x;
   const int lane = threadIdx.x;
   if (h >= n_hyp) return;
@@ -888,6 +938,11 @@ __global__ __launch_bounds__(64) void pnp_six_point_kernel(int n_hyp, int n, con
   }
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 4; ++j) proj_out[12 * h + 4 * i + j] = K[3 * i] * rt[j] + K[3 * i + 1] * rt[4 + j] + K[3 * i + 2] * rt[8 + j];
+  if (proj_neg_out) {      // what the reference scores when its det(rot) < 0 branch fired (campose:629-631): rot = R, loc = -C
+    for (int i = 0; i < 3; ++i) rt[4 * i + 3] = -rt[4 * i + 3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 4; ++j) proj_neg_out[12 * h + 4 * i + j] = K[3 * i] * rt[j] + K[3 * i + 1] * rt[4 + j] + K[3 * i + 2] * rt[8 + j];
+  }
 }
 
 __device__ __forceinline__ bool pnp_is_inlier(const double* P, const double* uv_pix, const double* X, int n, int i,
@@ -934,35 +989,86 @@ __global__ void gather_points_kernel(int n, const int* __restrict__ index, const
   X[i] = px[p]; X[(size_t)n + i] = py[p]; X[2 * (size_t)n + i] = pz[p]; X[3 * (size_t)n + i] = 1.0;
 }
 
+// Workspace of the split PnP class, one per stream (calls on one stream are ordered, so it is reused; it only grows and
+// lives until sfm_shutdown).
+struct PnpSplitCache { hipStream_t stream; double* xch; int* ctr; size_t xch_doubles; int views; };
+static std::vector<PnpSplitCache>& pnp_split_cache() { static std::vector<PnpSplitCache> c; return c; }
+static int pnp_split_workspace(hipStream_t s, int n_views, int kmax, PnpSplitWs* out) {
+  auto& cache = pnp_split_cache();
+  PnpSplitCache* e = nullptr;
+  for (auto& c : cache) if (c.stream == s) e = &c;
+  if (!e) { cache.push_back(PnpSplitCache{s, nullptr, nullptr, 0, 0}); e = &cache.back(); }
+  const size_t need = (size_t)n_views * 2 * kmax * 35;
+  if (need > e->xch_doubles) {
+    if (e->xch) { SFM_HIP(hipStreamSynchronize(s)); pool_free(e->xch); e->xch = nullptr; }
+    SFM_HIP(pool_alloc(reinterpret_cast<void**>(&e->xch), sizeof(double) * need));
+    e->xch_doubles = need;
+  }
+  if (n_views > e->views) {
+    if (e->ctr) { SFM_HIP(hipStreamSynchronize(s)); pool_free(e->ctr); e->ctr = nullptr; }
+    SFM_HIP(pool_alloc(reinterpret_cast<void**>(&e->ctr), sizeof(int) * (size_t)n_views));
+    e->views = n_views;
+  }
+  out->xch = e->xch; out->ctr = e->ctr; out->kmax = kmax;
+  return SFM_OK;
+}
+static void pnp_split_release() {
+  for (auto& c : pnp_split_cache()) { if (c.xch) pool_free(c.xch); if (c.ctr) pool_free(c.ctr); }
+  pnp_split_cache().clear();
+}
+
+// views of at least this many points are split over workgroups (measured: profiles/r4/time_pnp_stages.txt)
+static int pnp_split_min() {
+  static const int v = [] { const char* e = getenv("SFM_PNP_SPLIT_MIN"); const int x = e ? atoi(e) : 0; return x > 1024 ? x : 3000; }();
+  return v;
+}
+
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
                                  double* R_out, double* C_out, int* status, hipStream_t s, int narrowest, int widest) {
-  // Two size classes, each with its own launch over all views (a workgroup whose view belongs to the other class returns at
+  // Three size classes, each with its own launch over all views (a workgroup whose view belongs to another class returns at
   // once), so that the kernel a view runs on -- and with it every bit of its result -- depends on the view's own size and
   // not on what else is in the batch (a shard of a batch returns what the whole batch returns):
-  //   up to 1024 points   256 threads keep four points each in registers;
-  //   above               512 threads work out of LDS: all six values of a point up to 3 200 points (150 KB), the
-  //                       normalised key alone up to 9 600, nothing beyond (a view above the capacity of the chosen mode
-  //                       re-reads its points inside the kernel; the staging changes where values come from, not the values).
-  // `narrowest` / `widest`: the smallest and the largest view when the caller knows them (the host entry point has the
-  // offsets), 0 = unknown.  A class no view can be in is not launched.
+  //   up to 1024 points        256 threads keep four points each in registers;
+  //   up to pnp_split_min()-1  512 threads work out of LDS: all six values of a point up to 3 200 points (150 KB);
+  //   above                    the view is split over ceil(n / 1024) workgroups of the first form that exchange their 35
+  //                            sums once per iteration (pnp_nonlinear_kernel<256, 4, true>).
+  // `narrowest` / `widest`: the smallest and the largest view (the host entry point has the offsets; the device-pointer
+  // entry is told the largest, or reads the offsets back when it is not).  A class no view can be in is not launched.
   constexpr int kSmall = 1024, kAll = 0x7fffffff;
+  const int split_min = pnp_split_min();
   const bool small_class = narrowest <= kSmall;
-  const bool big_class = widest <= 0 || widest > kSmall;
+  const bool mid_class = widest > kSmall && narrowest < split_min;
+  const bool split_class = widest >= split_min;
   if (small_class)
     pnp_nonlinear_kernel<256, 4><<<n_views, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, 0, 0,
-                                                         0, big_class ? kSmall : kAll);
-  if (big_class) {
+                                                         0, kSmall);
+  if (mid_class) {
     static const bool attr = [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pnp_nonlinear_kernel<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       return true;
     }();
     (void)attr;
-    const int mode = widest <= 0 ? 2 : (widest <= 3200 ? 1 : (widest <= 9600 ? 2 : 0));
+    const int widest_mid = std::min(widest, split_min - 1);
+    const int mode = widest_mid <= 3200 ? 1 : (widest_mid <= 9600 ? 2 : 0);
     const int cap = mode == 1 ? 3200 : (mode == 2 ? 9600 : 0);
     const size_t lds = sizeof(double) * (size_t)cap * (mode == 1 ? 6 : 2);
     pnp_nonlinear_kernel<512, 2><<<n_views, 512, lds, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status, mode, cap,
-                                                          small_class ? kSmall + 1 : 0, kAll);
+                                                          kSmall + 1, split_min - 1);
+  }
+  if (split_class) {
+    const int kmax = (widest + kPnpSplitSlice - 1) / kPnpSplitSlice;
+    PnpSplitWs ws;
+    SFM_TRY(pnp_split_workspace(s, n_views, kmax, &ws));
+    SFM_HIP(hipMemsetAsync(ws.ctr, 0, sizeof(int) * (size_t)n_views, s));
+    // the slices of a view wait for each other inside the launch: keep a launch's workgroups within what is resident at
+    // once (sibling workgroups are neighbours in the grid; workgroups of views of other classes leave at once)
+    const int views_per_launch = std::max(1, 2 * ctx().num_cus / kmax);
+    for (int v0 = 0; v0 < n_views; v0 += views_per_launch) {
+      const int nv = std::min(views_per_launch, n_views - v0);
+      pnp_nonlinear_kernel<256, 4, true><<<nv * kmax, 256, 0, s>>>(offsets, total, uv_pix, X, K, R0, C0, lambda, iters, quirks, R_out, C_out, status,
+                                                                  0, 0, split_min, kAll, ws, v0);
+    }
   }
   SFM_HIP(hipGetLastError());
   return SFM_OK;
@@ -1021,6 +1127,8 @@ int sfm_shutdown(void) {
   if (!c.inited) return SFM_OK;
   (void)hipStreamSynchronize(c.stream);
   if (c.stream != c.own) (void)hipStreamSynchronize(c.own);
+  (void)hipDeviceSynchronize();      // the split-PnP workspaces belong to callers' streams
+  pnp_split_release();
   pool_release_all();
   if (c.own) (void)hipStreamDestroy(c.own);
   c = Context();
@@ -1174,8 +1282,17 @@ int sfm_pnp_nonlinear_batch_dev(int n_views, const int* d_offsets, int total, co
   }
   // the offsets live on the device: the caller says how large its largest view is (0: unknown -- both size classes are
   // launched; a view larger than the caller said is still refined, by the small-view kernel re-reading its points)
+  hipStream_t s = pick_stream(hip_stream);
+  int widest = max_view_points, narrowest = 0;
+  if (widest <= 0) {      // not told: the size classes are a function of the views' sizes, so read them (blocking once)
+    std::vector<int> off((size_t)n_views + 1);
+    SFM_HIP(hipMemcpyAsync(off.data(), d_offsets, sizeof(int) * ((size_t)n_views + 1), hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    widest = 1; narrowest = 0x7fffffff;
+    for (int v = 0; v < n_views; ++v) { widest = std::max(widest, off[v + 1] - off[v]); narrowest = std::min(narrowest, off[v + 1] - off[v]); }
+  }
   SFM_TRY(enqueue_pnp_nonlinear(n_views, d_offsets, total, d_uv_pix, d_X, d_K, d_R0, d_C0, lambda, iters, quirks, d_R_out,
-                                d_C_out, d_status, pick_stream(hip_stream), 0, max_view_points > 0 ? max_view_points : 0));
+                                d_C_out, d_status, s, narrowest, widest));
   return SFM_OK;
 }
 
@@ -1263,7 +1380,7 @@ int sfm_pnp_six_point_hypotheses(int n, const double* uv_pix, const double* X, c
   SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(12 * (size_t)n_hyp));
   SFM_TRY(dCnt.alloc(n_hyp));
-  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
+  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p, nullptr);
   pnp_score_kernel<<<n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
   SFM_HIP(hipGetLastError());
   SFM_TRY(dR.download(R_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_hyp, s));
@@ -1286,7 +1403,7 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const do
   SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
   SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(12 * (size_t)n_hyp));
   SFM_TRY(dCnt.alloc(n_hyp)); SFM_TRY(dMask.alloc(n));
-  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p);
+  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p, nullptr);
   pnp_score_kernel<<<n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
   SFM_HIP(hipGetLastError());
   std::vector<int> counts(n_hyp);
@@ -1312,6 +1429,57 @@ int sfm_pnp_linear_ransac(int n, const double* uv_pix, const double* X, const do
   SFM_HIP(hipMemcpyAsync(R_out, dR.p + 9 * (size_t)best, 9 * sizeof(double), hipMemcpyDeviceToHost, s));
   SFM_HIP(hipMemcpyAsync(C_out, dC.p + 3 * (size_t)best, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
   SFM_TRY(stream_sync(s));
+  return SFM_OK;
+}
+
+int sfm_pnp_ransac_evaluate(int n, const double* uv_pix, const double* X, const double K[9], int n_hyp, const int* samples,
+                            double threshold, double* R_out, double* C_out, int* counts, int* counts_neg) {
+  SFM_TRY(ensure_init());
+  if (n < 6 || n_hyp < 1) { set_error("sfm_pnp_ransac_evaluate: need n >= 6 points and n_hyp >= 1 (n=%d n_hyp=%d)", n, n_hyp); return SFM_E_SHAPE; }
+  for (int i = 0; i < 6 * n_hyp; ++i)
+    if (samples[i] < 0 || samples[i] >= n) { set_error("sfm_pnp_ransac_evaluate: sample index %d out of range", samples[i]); return SFM_E_SHAPE; }
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dUV, dX, dK, dR, dC, dP;
+  DevBuf<int> dS, dCnt;
+  SFM_TRY(dUV.upload(uv_pix, 3 * (size_t)n, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s)); SFM_TRY(dK.upload(K, 9, s));
+  SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
+  SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(24 * (size_t)n_hyp));
+  SFM_TRY(dCnt.alloc(2 * (size_t)n_hyp));
+  // projections of the pose (R, C) in the first n_hyp blocks, of (R, -C) behind them; one scoring launch over both
+  pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, dUV.p, dX.p, dK.p, dR.p, dC.p, dP.p, dP.p + 12 * (size_t)n_hyp);
+  pnp_score_kernel<<<2 * n_hyp, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dCnt.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dR.download(R_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_hyp, s));
+  SFM_HIP(hipMemcpyAsync(counts, dCnt.p, sizeof(int) * n_hyp, hipMemcpyDeviceToHost, s));
+  SFM_HIP(hipMemcpyAsync(counts_neg, dCnt.p + n_hyp, sizeof(int) * n_hyp, hipMemcpyDeviceToHost, s));
+  SFM_TRY(stream_sync(s));
+  return SFM_OK;
+}
+
+int sfm_pnp_inlier_mask(int n, const double* uv_pix, const double* X, const double K[9], const double R[9], const double C[3],
+                        double threshold, int* inlier_mask, int* n_inliers) {
+  SFM_TRY(ensure_init());
+  if (n < 1) { set_error("sfm_pnp_inlier_mask: n < 1"); return SFM_E_SHAPE; }
+  // proj = K @ [R^T | R^T @ -C]  (campose:538), 12 doubles: formed on the host side of the library, scored on the device
+  double rt[12], P[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) rt[4 * i + j] = R[3 * j + i];
+    rt[4 * i + 3] = R[0 + i] * -C[0] + R[3 + i] * -C[1] + R[6 + i] * -C[2];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) P[4 * i + j] = K[3 * i] * rt[j] + K[3 * i + 1] * rt[4 + j] + K[3 * i + 2] * rt[8 + j];
+  hipStream_t s = ctx().stream;
+  DevBuf<double> dUV, dX, dP;
+  DevBuf<int> dMask;
+  SFM_TRY(dUV.upload(uv_pix, 3 * (size_t)n, s)); SFM_TRY(dX.upload(X, 4 * (size_t)n, s)); SFM_TRY(dP.upload(P, 12, s));
+  SFM_TRY(dMask.alloc(n));
+  pnp_inlier_mask_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dP.p, dUV.p, dX.p, threshold, dMask.p);
+  SFM_HIP(hipGetLastError());
+  SFM_TRY(dMask.download(inlier_mask, n, s));
+  SFM_TRY(stream_sync(s));
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) cnt += inlier_mask[i] != 0;
+  if (n_inliers) *n_inliers = cnt;
   return SFM_OK;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "sfm_version", "sfm_init", "sfm_shutdown", "sfm_set_stream", "sfm_synchronize", "sfm_last_error",
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
-    "sfm_pnp_linear_ransac", "sfm_pnp_six_point_hypotheses",
+    "sfm_pnp_linear_ransac", "sfm_pnp_six_point_hypotheses", "sfm_pnp_ransac_evaluate", "sfm_pnp_inlier_mask",
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
@@ -310,6 +310,33 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
                                     float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
                                     ctypes.byref(best)))
     return rot, loc.reshape(3, 1), np.flatnonzero(mask).tolist(), best.value
+
+
+def pnp_ransac_evaluate(uv_pix, pts_h, intrinsic, samples, threshold):
+    """Every six-point hypothesis: (rot (n_hyp,3,3), loc (n_hyp,3), inlier counts under (R, C), inlier counts under (R, -C))."""
+    uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic)
+    samples = i32(samples).reshape(-1, 6)
+    n, n_hyp = uv_pix.shape[1], samples.shape[0]
+    rot = np.empty((n_hyp, 3, 3)); loc = np.empty((n_hyp, 3))
+    cnt = np.empty(n_hyp, dtype=np.int32); cnt_neg = np.empty(n_hyp, dtype=np.int32)
+    lib = load()
+    lib.sfm_pnp_ransac_evaluate.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_double, _dp, _dp, _ip, _ip]
+    check(lib.sfm_pnp_ransac_evaluate(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples),
+                                      float(threshold), dptr(rot), dptr(loc), iptr(cnt), iptr(cnt_neg)))
+    return rot, loc, cnt, cnt_neg
+
+
+def pnp_inlier_mask(uv_pix, pts_h, intrinsic, rot, loc, threshold):
+    """Inlier index list of one pose (pixel reprojection error below `threshold`, campose_processor.py:544-554)."""
+    uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic); rot = f64(rot); loc = f64(loc).reshape(3)
+    n = uv_pix.shape[1]
+    mask = np.empty(n, dtype=np.int32)
+    cnt = ctypes.c_int()
+    lib = load()
+    lib.sfm_pnp_inlier_mask.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, _ip, _ip]
+    check(lib.sfm_pnp_inlier_mask(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), dptr(rot), dptr(loc), float(threshold),
+                                  iptr(mask), ctypes.byref(cnt)))
+    return np.flatnonzero(mask).tolist()
 
 
 def pnp_six_point_hypotheses(uv_pix, pts_h, intrinsic, samples, threshold):

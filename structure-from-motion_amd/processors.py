@@ -30,6 +30,7 @@ import numpy as np
 from . import native
 from .geometry import (pack_cameras, quaternion_to_rotation_unchecked, quaternions_to_rotations)
 from .observations import KeyCache, ObservationTracker, build_observations, gather_normalised_keys
+from .q13 import det_branch_fires, reference_winner
 from .sampling import sample_indices
 
 
@@ -127,6 +128,9 @@ class HipCamposeMixin:
     """Hot-path methods of CamposeProcessor (campose_processor.py:11-808)."""
 
     quirk_flags = native.QUIRKS_REFERENCE        # bug-compatible by default (SURVEY.md Appendix A)
+    reproduce_q13 = True                         # the RANSAC winner the reference's LAPACK would have left standing (q13.py);
+                                                 # False: the sane RANSAC (every hypothesis with its sign-invariant centre)
+    ransac_last = None                           # diagnostics of the last RANSAC call
 
     def nonlinear_estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat,
                                         init_rot, init_loc, damping_factor=None, iteration=None):
@@ -166,8 +170,28 @@ class HipCamposeMixin:
             logging.warning('%s : required equal or more than six points %d', self.__class__.__name__, num_pts)
             raise ValueError("required equal or more than six points {}".format(num_pts))
         samples = sample_indices(num_pts, 6, ransac_config.iteration, as_array=True)       # = [random.sample(range(num_pts), 6) ...], campose:531
-        rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
+        if not self.reproduce_q13:
+            rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
+                key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+            return inlier_indices, rot, loc
+        # Quirk Q13 (q13.py): the device solves and scores every hypothesis, under its centre C and under -C; which of the
+        # two the reference would have scored is its LAPACK's decision, asked of NumPy for the hypotheses that can still win
+        rots, locs, counts, counts_neg = native.pnp_ransac_evaluate(
             key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+        kinv = np.linalg.inv(intrinsic_mat)
+
+        def fires(h):
+            idx = samples[h].tolist()
+            return det_branch_fires(kinv @ key_2d_pts[:, idx], tri_3d_pts[:, idx])        # campose:532-535
+
+        best, fired = reference_winner(counts, counts_neg, fires)
+        self.ransac_last = {"hypothesis": best, "q13_fired": fired,
+                            "sane_winner": int(np.argmax(counts)) if counts.max() > 0 else -1}
+        if best < 0:                                   # no hypothesis has an inlier: the initial pose (campose:519-522)
+            return [], np.identity(3), np.zeros((3, 1))
+        rot = rots[best].copy()
+        loc = (-locs[best] if fired else locs[best]).reshape(3, 1).copy()
+        inlier_indices = native.pnp_inlier_mask(key_2d_pts, tri_3d_pts, intrinsic_mat, rot, loc, ransac_config.inlier_threshold)
         return inlier_indices, rot, loc
 
     def estimate_cam_pose_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat,

@@ -301,3 +301,34 @@ def test_bulk_ransac_samples_replay_random_sample_exactly(sfm):
     want = [random.sample(range(3000), 6) for _ in range(300)]
     assert got == want and random.random() == after
     assert sampling._verified is True                         # the bulk path is what ran, not the fallback
+
+
+def test_q13_sign_oracle_and_winner_rule_against_the_reference_chain(sfm, golden):
+    """q13.det_branch_fires is the reference's det(rot) < 0 decision (campose_processor.py:629) for every one of the 3 600
+    hypotheses of the captured per-view chains (g10: instrumented replay of the real RANSAC loop), and
+    q13.reference_winner picks the hypothesis the reference kept -- also when scores tie, when the winner is itself a
+    hypothesis whose branch fired (sequence 62, view 5), and when nothing has an inlier."""
+    q13 = sfm.q13
+    for seed in (61, 62, 63):
+        g = golden("g10_incremental_%d.npz" % seed)
+        kinv = np.linalg.inv(g["K"])
+        for c in range(2, int(g["n_views"])):
+            pre = "v%d_" % c
+            fired, counts, samples, idx = g[pre + "hyp_fired"], g[pre + "hyp_counts"], g[pre + "hyp_samples"], g[pre + "pnp_index"]
+            tri = g["v%d_ba_pts" % (c - 1)][:, idx]            # the points the view's PnP saw = the state after the previous BA
+            key = g["uv"][c][:, idx]
+            got = np.array([q13.det_branch_fires(kinv @ key[:, s.tolist()], tri[:, s.tolist()]) for s in samples])
+            assert np.array_equal(got, fired), (seed, c)
+            # the device's side of the bargain, emulated: a spared hypothesis scores `counts` under C, a fired one under -C;
+            # give the other sign a LARGER count for every third hypothesis so that the lazy walk has to ask
+            other = np.where(np.arange(counts.shape[0]) % 3 == 0, counts.max() + 5, 0)
+            cpos = np.where(fired, other, counts); cneg = np.where(fired, counts, other)
+            asked = []
+            h, f = q13.reference_winner(cpos, cneg, lambda k: (asked.append(k), bool(fired[k]))[1])
+            assert h == int(np.argmax(counts)) and f == bool(fired[h]), (seed, c)
+            assert len(asked) < counts.shape[0]
+    assert q13.reference_winner(np.zeros(5, int), np.zeros(5, int), lambda k: False) == (-1, False)
+    # ties: the FIRST hypothesis with the best score wins (strict '>' in campose:554)
+    assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 0, 9]), lambda k: False) == (1, False)
+    assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 0, 9]), lambda k: k == 3) == (3, True)
+    assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 7, 9]), lambda k: k == 1) == (2, False)

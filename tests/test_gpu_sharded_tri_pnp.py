@@ -60,6 +60,35 @@ def test_pnp_sharded_by_view_equals_unsharded(hip, sfm, oracle, world, sizes):
         assert rel(rot[v], r_or) < 1e-9 and rel(loc[v], c_or.reshape(3)) < 1e-9, v
 
 
+@pytest.mark.parametrize("world,sizes", [(2, [3000, 40, 5000, 2999]), (3, [9601, 1024, 3001])])
+def test_pnp_split_views_sharded_equal_unsharded_and_match_the_oracle(hip, sfm, oracle, world, sizes):
+    """Round 4: views of 3 000 points and more are split over ceil(n / 1024) workgroups that exchange their 35 sums once per
+    iteration (campose_processor.py:378-422 is one reduction per iteration).  The class is chosen by the view's own size, the
+    partial sums are added in slice order: a view's result is the same bits whether it runs alone, in a batch or in a
+    rank's shard of a batch -- and it is the oracle's result."""
+    sh = sfm.sharding
+    offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=23)
+    rot, loc, st = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, 4)
+    assert not st.any()
+    parts = _emulate(world, lambda r, g: sh.ShardedPnp(r, world, gather=g),
+                     lambda p: p.nonlinear_estimate(offsets, uvp, xs, ks, r0, c0, 5.0, 4))
+    packed = np.hstack(parts)
+    assert np.array_equal(packed[0:9].T.reshape(-1, 3, 3), rot) and np.array_equal(packed[9:12].T, loc)
+    for v, n in enumerate(sizes):
+        a, b = int(offsets[v]), int(offsets[v + 1])
+        alone_r, alone_c = hip.pnp_nonlinear(uvp[:, a:b], xs[:, a:b], ks[v], r0[v], c0[v], 5.0, 4)
+        assert np.array_equal(alone_r, rot[v]) and np.array_equal(alone_c.reshape(3), loc[v]), v
+        r_or, c_or = oracle.nonlinear_pnp(uvp[:, a:b], xs[:, a:b], ks[v], r0[v], c0[v].reshape(3, 1), 5.0, 4)
+        assert rel(rot[v], r_or) < 1e-9 and rel(loc[v], c_or.reshape(3)) < 1e-9, v
+    # many iterations through the hand-over (the counter is monotone over a launch) and all four quirk combinations
+    a, b = int(offsets[0]), int(offsets[1])
+    for quirks in (0, 1, 2, 3):
+        got_r, got_c = hip.pnp_nonlinear(uvp[:, a:b], xs[:, a:b], ks[0], r0[0], c0[0], 5.0, 300, quirks)
+        again_r, again_c = hip.pnp_nonlinear(uvp[:, a:b], xs[:, a:b], ks[0], r0[0], c0[0], 5.0, 300, quirks)
+        assert np.array_equal(got_r, again_r) and np.array_equal(got_c, again_c)       # slice order, not arrival order
+        assert np.all(np.isfinite(got_r)) and abs(np.linalg.det(got_r) - 1.0) < 1e-12
+
+
 def test_device_pointer_entry_points_match_host_entry_points(hip, sfm):
     """sfm_tri_nonlinear_dev / sfm_tri_linear_dev / sfm_triangulate_dev / sfm_pnp_nonlinear_batch_dev: torch tensors in
     HBM, the caller's stream, no implicit synchronisation -- the same kernels as the host-pointer calls, bit for bit."""

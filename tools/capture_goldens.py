@@ -545,6 +545,135 @@ def g5h_pnp_hypotheses():
                         counts=np.array(cnts, dtype=np.int32), branch=np.array(branch), threshold=cfg.inlier_threshold)
 
 
+# ---------------------------------------------------------------------------------------
+class _ChainView:                # fields the per-view chain touches: ba:191-267 (cam_proj for triangulate, update_cam_pose)
+    def __init__(self, rot, loc, k, kps):
+        self.k, self.key_pts = k, kps
+        self.update_cam_pose(rot, loc)
+
+    def update_cam_pose(self, rot, loc):     # view_processor.py:61-69
+        self.rot, self.loc = rot, loc
+        self.cam_pose = np.hstack((rot, loc))
+        self.cam_proj = self.k @ np.hstack((rot.T, rot.T @ -loc))
+
+
+def _rng_digest():
+    import hashlib
+    return hashlib.sha256(repr(random.getstate()).encode()).hexdigest()
+
+
+def g10_incremental():
+    """BASELINE config 5's call chain pinned by the REAL classes: per registered view
+    CamposeProcessor.estimate_cam_pose_pnp (seeded RANSAC + nonlinear PnP, campose:192-246) ->
+    View.update_cam_pose -> TriangulationProcessor.triangulate (tri:31-88) -> add_tri_pt ->
+    BaProcessor.__execute_bundle_adjustment (ba:274-439), view after view on ONE stream of Python's global RNG
+    (seeded by RansacConfig, utils.py:172-174).  Synthetic 6-view sequences (the upenn BMPs need SIFT), three seeds;
+    8 % of every view's keys of already-known points are gross outliers so that the inlier lists are not trivial.
+    Stored per view: the inlier list, the PnP pose, the new points, the state after BA, the RNG digest, and -- from an
+    instrumented replay of the RANSAC loop with the RNG state restored afterwards -- every hypothesis' six-point
+    sample, whether campose:629-631 (quirk Q13) fired for it, and its inlier count."""
+    for seed in (61, 62, 63):
+        n_views, n_pts = 6, 150
+        sc = scenes.make_scene(n_views, n_pts, 1.0, seed=seed, pixel_noise=0.3)
+        K = sc.intrinsic
+        rng = np.random.default_rng(1000 + seed)
+        per = (n_pts + n_views - 2) // (n_views - 1)
+        birth = 1 + np.arange(n_pts) // per
+        uv = []
+        for c in range(n_views):
+            u = np.vstack((sc.uv_pix[:, sc.cam_idx == c], np.ones((1, n_pts))))
+            known_before = np.flatnonzero(birth < c)          # the PnP input set of view c; never used to triangulate from c
+            if known_before.size:
+                bad = rng.choice(known_before, size=max(1, int(0.08 * known_before.size)), replace=False)
+                u[0:2, bad] += rng.normal(0, 30.0, (2, bad.size))
+            uv.append(u)
+        from scipy.spatial.transform import Rotation
+        rots = [ref_utils.convert_quaternion_to_rotation(sc.cams_true[c, 3:7].reshape(4, 1)) for c in range(n_views)]
+        locs = [sc.cams_true[c, 0:3].reshape(3, 1).copy() for c in range(n_views)]
+        rot1 = rots[1] @ Rotation.from_rotvec(rng.normal(0, 0.002, 3)).as_matrix()      # second view: "two-view initialisation"
+        loc1 = locs[1] + rng.normal(0, 0.01, (3, 1))
+
+        cfg = quiet(ref_utils.RansacConfig, 8.0, 0.99, 0.75, 6, 300)                     # seeds Python's RNG with -1
+        cp = ref_cam.CamposeProcessor(cfg, 5, 300)                                       # ba_processor.py:486
+        tp = ref_tri.TriangulationProcessor()                                            # 0.5, 100
+        vp = _VP(); vp.view_list = []
+        tracks = []
+        kt = _KT(tracks)
+        bp = ref_ba.BaProcessor(vp, kt, None, tp, cp, iteration=3, damping_factor=5)
+        six = getattr(cp, "_CamposeProcessor__estimate_six_pts")
+
+        def add_view(c, rot, loc):
+            kps = [_KP(-1.0, -1.0)] + [_KP(float(uv[c][0, j]), float(uv[c][1, j])) for j in range(n_pts)]
+            vp.view_list.append(_ChainView(rot, loc, K.copy(), kps))
+            tracks.append(ref_kt.KeyTrack(n_views, n_pts + 1, c))
+
+        out = dict(K=K, n_views=n_views, n_pts=n_pts, birth=birth, uv=np.array(uv), rot0=rots[0], loc0=locs[0], rot1=rot1, loc1=loc1,
+                   ransac=np.array([8.0, 0.99, 0.75, 6, 300]), pnp=np.array([5.0, 300.0]), tri=np.array([0.5, 100.0]), ba=np.array([5.0, 3.0]),
+                   rng_digest_start=np.array(_rng_digest()))
+        add_view(0, rots[0].copy(), locs[0].copy())
+        known = np.zeros(n_pts, dtype=bool)
+        t_seed = time.time()
+        for c in range(1, n_views):
+            pre = "v%d_" % c
+            if known.any():
+                idx = np.flatnonzero(known)
+                key2d, tri3d = uv[c][:, idx], tp.tri_pts[:, idx]
+                # instrumented replay of the RANSAC loop (campose:524-560), RNG state restored afterwards
+                state = random.getstate()
+                kinv = np.linalg.inv(K)
+                samples, fired, counts = [], [], []
+                for _ in range(cfg.iteration):
+                    s6 = random.sample(range(idx.size), 6)
+                    k6 = kinv @ key2d[:, s6]
+                    rot, loc = six(k6, tri3d[:, s6])
+                    w = np.zeros((12, 12))
+                    for i in range(6):
+                        x, y, z = k6[:, i]; xx = tri3d[:, s6[i]]
+                        w[2 * i, 0:4] = z * xx; w[2 * i, 8:12] = -x * xx
+                        w[2 * i + 1, 4:8] = z * xx; w[2 * i + 1, 8:12] = -y * xx
+                    cam_mat = np.linalg.svd(w)[2].T[:, -1].reshape(3, 4)
+                    uu, ss, vvh = np.linalg.svd(cam_mat[:, 0:3])
+                    raw = (uu @ vvh).T
+                    f = bool(np.linalg.det(raw) < 0)
+                    assert np.array_equal(rot, -raw if f else raw)
+                    proj = K @ np.hstack((rot.T, rot.T @ -loc))
+                    q = proj @ tri3d
+                    q = q / q[2]
+                    err = np.sqrt(np.sum((key2d - q) ** 2, axis=0))
+                    samples.append(s6); fired.append(f); counts.append(int(np.sum(err < cfg.inlier_threshold)))
+                random.setstate(state)
+                out[pre + "rng_before_pnp"] = np.array(_rng_digest())
+                inl, r_new, c_new = quiet(cp.estimate_cam_pose_pnp, key2d, tri3d, K)          # ba_processor.py:191
+                out[pre + "hyp_samples"] = np.array(samples, dtype=np.int32)
+                out[pre + "hyp_fired"] = np.array(fired)
+                out[pre + "hyp_counts"] = np.array(counts, dtype=np.int32)
+                out[pre + "pnp_index"] = idx.astype(np.int32)
+                out[pre + "inliers"] = np.array(inl, dtype=np.int32)
+                out[pre + "pnp_rot"] = np.array(r_new); out[pre + "pnp_loc"] = np.array(c_new).reshape(3, 1)
+                best = int(np.argmax(counts))
+                print("    seed %d view %d: %d known, %d inliers, %d hypotheses fired Q13 (best fired count %d), winner #%d with %d" % (
+                    seed, c, idx.size, len(inl), int(np.sum(fired)), max([n for n, f in zip(counts, fired) if f] or [0]), best, counts[best]))
+                assert counts[best] == len(inl)
+            else:
+                r_new, c_new = rot1, loc1
+            add_view(c, r_new, c_new)
+            out[pre + "rng_after_pnp"] = np.array(_rng_digest())
+            new = np.flatnonzero(birth == c)
+            views = vp.view_list
+            pts_new = quiet(tp.triangulate, [views[c - 1].cam_proj, views[c].cam_proj], [uv[c - 1][:, new], uv[c][:, new]])      # ba:246
+            out[pre + "new_pts"] = np.array(pts_new)
+            tp.add_tri_pt(np.array(pts_new))                                                                               # ba:262
+            known[new] = True
+            ids = np.flatnonzero(known)
+            for v in range(c + 1):
+                tracks[v].table[v, 1 + ids] = ids            # key index = point + 1 (key 0 is a dummy: Q3)
+            quiet(bp._BaProcessor__execute_bundle_adjustment)                                                               # ba:267
+            out[pre + "ba_rots"] = np.array([v.rot for v in views]); out[pre + "ba_locs"] = np.array([v.loc for v in views])
+            out[pre + "ba_pts"] = np.array(tp.tri_pts)
+        print("  g10 seed %d: %.1fs" % (seed, time.time() - t_seed))
+        np.savez_compressed(os.path.join(OUT, "g10_incremental_%d.npz" % seed), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-slow", action="store_true")
@@ -558,7 +687,7 @@ def main():
     steps = [("g1", lambda: g1_jac_cam(rng)), ("g2", lambda: g2_jac_pt(rng)), ("g3", lambda: g3_quat(rng)),
              ("g4", lambda: g4_tri(rng, slow)), ("g5", lambda: g5_pnp(rng, slow)), ("g6", lambda: g6_ba(slow)),
              ("g5h", g5h_pnp_hypotheses),
-             ("g7", lambda: g7_visible(rng)), ("g8", g8_fundamental), ("g9", g9_two_view_pose)]
+             ("g7", lambda: g7_visible(rng)), ("g8", g8_fundamental), ("g9", g9_two_view_pose), ("g10", g10_incremental)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue
