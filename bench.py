@@ -331,7 +331,20 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
     if args.debug:
         engine.prob.set_option(native.OPT_DEBUG, args.debug)
-    ba = sfm.sharding.ShardedBa(engine, make_all_reduce(ctx, collective), world)
+    if collective == "library":
+        # the library owns the communicator (sfm_comm_create: ncclCommInitRank on this rank's GPU) and issues the all-reduce
+        # itself inside sfm_ba_iterate: K iterations = ONE C-ABI call per rank, no Python between them.  The 128-byte id
+        # travels over the process group that torch.distributed already set up (any channel would do).
+        if rehearsal:
+            raise SystemExit("--collective library needs one GPU per rank (RCCL refuses two ranks on one device): not available under SFM_BENCH_REHEARSAL")
+        ident = [native.comm_unique_id() if rank == 0 else None]
+        if use_dist:
+            dist.broadcast_object_list(ident, src=0)
+        comm = native.Comm(world, rank, ident[0])
+        engine.attach_comm(comm)
+        ba = sfm.sharding.ShardedBa(engine, None, world)
+    else:
+        ba = sfm.sharding.ShardedBa(engine, make_all_reduce(ctx, collective), world)
     sync = ctx.sync
 
     def gather_state():
@@ -1007,9 +1020,10 @@ def main():
                     help="C3 with N > 1: which figure is `value` (auto = weak: 20 000 points per rank; strong = the fixed 50 x 20k scene split "
                          "over the ranks); the other one is timed as well and reported next to it")
     ap.add_argument("--single-scaling", action="store_true", help="C3 with N > 1: time only the figure --scaling names")
-    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_broadcast"],
-                    help="the per-iteration exchange of [S | rhs]; reduce_broadcast is the repair the bench falls back to by itself when "
-                         "the ranks' cameras drift apart under allreduce")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_broadcast", "library"],
+                    help="the per-iteration exchange of [S | rhs]: allreduce = torch.distributed (RCCL) between two C-ABI calls per iteration; "
+                         "reduce_broadcast = the repair the bench falls back to by itself when the ranks' cameras drift apart under allreduce; "
+                         "library = the library's own RCCL communicator inside sfm_ba_iterate (one C-ABI call for all K iterations)")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "TRI", "PNP", "C5"])
     ap.add_argument("--pts", type=int, default=None, help="override points per rank / per view (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -35,6 +35,7 @@ extern "C" {
 #define SFM_E_HIP           -5   /* HIP runtime error */
 #define SFM_E_NO_DEVICE     -6   /* no gfx950 device visible */
 #define SFM_E_HANDLE        -7   /* null / destroyed problem handle */
+#define SFM_E_RCCL          -9   /* the RCCL library could not be loaded, or one of its calls failed (sfm_comm_*, sfm_ba_set_comm) */
 #define SFM_E_RANK          -8   /* rank-2 projection of a fundamental / essential matrix is not rank 2 -> ValueError (epipolar_processor.py:187-190, 90-93) */
 
 /* ---- quirk bits; the reference's behaviour = SFM_QUIRKS_REFERENCE ------ */
@@ -82,7 +83,10 @@ extern "C" {
 /* ---- items of sfm_ba_info -------------------------------------------------------------------------- */
 #define SFM_INFO_SCHUR_KERNEL  1  /* SFM_SCHUR_PAIRS / SFM_SCHUR_MFMA / SFM_SCHUR_ROWS: the product kernel the next iteration launches
                                    * (asking builds the row-panel product's work split if that is the candidate, so the answer is
-                                   * the kernel that will run, not the one that was hoped for) */
+                                   * the kernel that will run, not the one that was hoped for).  NOT a pure query: when it has
+                                   * to build that split it completes a deferred back substitution (as sfm_ba_flush does) and
+                                   * enqueues kernels on the problem's stream -- do not ask between sfm_ba_linearize_reduce and
+                                   * sfm_ba_solve_update of one iteration, nor inside a stream capture */
 #define SFM_INFO_UPLOAD_BYTES  2  /* host -> device bytes moved on behalf of this handle since sfm_ba_create */
 #define SFM_INFO_N_CAMS        3
 #define SFM_INFO_N_PTS         4
@@ -337,6 +341,23 @@ int sfm_ba_stream(sfm_ba_problem* p, void** hip_stream);
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld);
 /* Bind an externally owned DEVICE buffer (e.g. a torch tensor) as the reduced buffer. */
 int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles);
+
+/* ---- the exchange step inside the library ("library owns its RCCL communicators") --------------
+ * One process per GPU.  Rank 0 calls sfm_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the
+ * application has (MPI, a file, torch.distributed ...); every rank then calls sfm_comm_create (ncclCommInitRank on the
+ * device of sfm_init) and attaches the communicator to its shard's problem.  From then on sfm_ba_iterate IS the sharded
+ * loop: per iteration linearise + partial reduce, ncclAllReduce(SUM, double) of the packed [S | rhs] buffer on the
+ * problem's stream, replicated atomic-free solve, back substitution of the rank's own points -- K iterations enqueued by
+ * ONE call, no host code between them, a plain C program included.  RCCL is loaded with dlopen on first use (librccl.so.1
+ * / librccl.so: a process that already carries torch's copy gets that one); the library has no link-time dependency on it.
+ * The reference has no distributed code; the algebra is ba_processor.py:376-406 (sums over points). */
+typedef struct sfm_comm sfm_comm;
+int sfm_comm_unique_id(char id_out[128]);
+int sfm_comm_create(int world_size, int rank, const char id[128], sfm_comm** out);
+int sfm_comm_destroy(sfm_comm* comm);
+/* Attach (or, with NULL, detach) a communicator: the problem's iterations then all-reduce the reduced buffer that is
+ * bound at that moment (the library's own, or a caller's: sfm_ba_bind_reduced_buffer). */
+int sfm_ba_set_comm(sfm_ba_problem* p, sfm_comm* comm);
 
 /* Parity hooks: per-observation terms and the reduced system at the given state (one linearisation,
  * ba_processor.py:317-382).  S is (7V x 7V) row-major (both triangles filled), rhs (7V). */

@@ -145,6 +145,7 @@ struct sfm_ba_problem {
   int timing = 0;            // bitmask over SFM_K_* of the kernel classes bracketed by hipEvents
   int timing_stride = 1;     // ... every stride-th time they run (an event pair costs ~11 us of stream bubbles on this stack)
   double* own_red = nullptr; // library-owned reduced buffer (dev.red may point to a caller's tensor)
+  sfm_comm* comm = nullptr;  // library-owned RCCL communicator (sfm_ba_set_comm): the iterations all-reduce [S | rhs] themselves
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
   int* schur_blk_ptr = nullptr;  // [N][nblk + 1] first observation of a point in each 18-camera block (sparse path)
@@ -190,6 +191,7 @@ void ba_graph_drop(sfm_ba_problem* p); // forget the captured iteration bodies
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
 bool ba_can_fuse(const sfm_ba_problem* p);
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras
+int comm_all_reduce_f64(sfm_comm* comm, double* buf, size_t count, hipStream_t s);      // sfm_comm.hip
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);
 void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out);
 }  // namespace sfm

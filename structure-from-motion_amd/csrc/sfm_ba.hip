@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_cam(CamPrep& dst, const CamPrep* src) {
 // THREADS = 64 (one wave per workgroup) is the deterministic variant: the camera accumulators in LDS then receive
 // their ds_add_f64 from a single instruction stream, in program order.
 template <int G, int LDS_MODE, bool DENSE_Z, bool FUSED, int THREADS = 256>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
+__global__ __launch_bounds__(THREADS) void ba_linearize_kernel(BaDev d, int cur, double lambda, int quirks) {
   static_assert(!FUSED || LDS_MODE == 2, "the fused kernel keeps both camera sets in LDS");
   extern __shared__ double lds[];
   unsigned long long* stamp = (d.stamps && blockIdx.x == 0 && threadIdx.x == 0) ? d.stamps + 192 : nullptr;
@@ -584,7 +584,7 @@ static int capture_body(sfm_ba_problem* p, double lambda, int quirks) {
 // the last one is flushed before returning.  With SFM_OPT_GRAPH the iterations after the first are graph replays
 // (two graphs: the camera slots alternate).
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks) {
-  const bool graphs = p->use_graph && p->timing == 0 && p->stream != nullptr && ba_can_fuse(p);
+  const bool graphs = p->use_graph && p->timing == 0 && p->stream != nullptr && ba_can_fuse(p) && p->comm == nullptr;
   if (graphs && (lambda != p->graph_lambda || quirks != p->graph_quirks)) {
     ba_graph_drop(p);
     p->graph_lambda = lambda;
@@ -604,6 +604,8 @@ int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirk
       continue;
     }
     SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    // sharded loop inside the library: this rank's partial [S | rhs] -> the sum over all ranks, on the problem's stream
+    if (p->comm) SFM_TRY(comm_all_reduce_f64(p->comm, p->dev.red, red_size(p->dev.nbk), p->stream));
     SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));
   }
   return ba_flush(p);

@@ -642,6 +642,14 @@ int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_do
   return SFM_OK;
 }
 
+int sfm_ba_set_comm(sfm_ba_problem* p, sfm_comm* comm) {
+  SFM_TRY(check_problem(p));
+  SFM_TRY(ba_flush(p));
+  ba_graph_drop(p);          // a captured iteration body has no collective in it
+  p->comm = comm;
+  return SFM_OK;
+}
+
 int sfm_ba_kernel_time(sfm_ba_problem* p, int kernel_id, double* total_ms, int* launches) {
   SFM_TRY(check_problem(p));
   if (kernel_id < 0 || kernel_id >= SFM_K_COUNT) { set_error("bad kernel id %d", kernel_id); return SFM_E_SHAPE; }

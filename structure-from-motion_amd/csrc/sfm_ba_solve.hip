@@ -728,7 +728,7 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
     if (lo > 0) {
       // one slice = one writer per output, no atomics: also whenever a caller's reduced buffer is bound, i.e. the
       // multi-GPU mode, where every rank repeats this solve and all of them must end on bit-identical cameras
-      const bool replicated = p->dev.red != p->own_red;
+      const bool replicated = p->dev.red != p->own_red || p->comm != nullptr;
       const int slices = (p->deterministic || replicated || hi - lo <= 16) ? 1 : std::min(4, (hi - lo + 15) / 16 + 1);
       ba_back_update_kernel<<<dim3(lo, slices), 256, 0, s>>>(d, lo, hi);
     }

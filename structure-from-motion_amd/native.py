@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_HIP_LIBRARY") or os.path.join(_HERE, "libsfm_hip.so")
 
 OK = 0
-E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK = -1, -2, -3, -4, -5, -6, -7, -8
+E_SHAPE, E_BAD_ROTATION, E_QW_ZERO, E_SQRT_DOMAIN, E_HIP, E_NO_DEVICE, E_HANDLE, E_RANK, E_RCCL = -1, -2, -3, -4, -5, -6, -7, -8, -9
 Q1_PNP_ROW_OVERLAP, Q2_LOC_JAC_SIGN, QUIRKS_REFERENCE = 1, 2, 3
 SCHUR_AUTO, SCHUR_PAIRS, SCHUR_MFMA, SCHUR_ROWS = 0, 1, 2, 3
 OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC, OPT_GRAPH, OPT_TIMING_STRIDE = 1, 2, 3, 4, 5, 6
@@ -29,6 +29,7 @@ EXPORTS = (
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_pnp_linear_ransac", "sfm_pnp_six_point_hypotheses", "sfm_pnp_ransac_evaluate", "sfm_pnp_inlier_mask",
+    "sfm_comm_unique_id", "sfm_comm_create", "sfm_comm_destroy", "sfm_ba_set_comm",
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
@@ -312,6 +313,40 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
     return rot, loc.reshape(3, 1), np.flatnonzero(mask).tolist(), best.value
 
 
+def comm_unique_id():
+    """128 opaque bytes identifying a new RCCL communicator (rank 0 calls this and hands them to the other ranks)."""
+    buf = ctypes.create_string_buffer(128)
+    lib = load()
+    lib.sfm_comm_unique_id.argtypes = [ctypes.c_char_p]
+    check(lib.sfm_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """A library-owned RCCL communicator of this process' GPU (sfm_comm_create / sfm_comm_destroy)."""
+
+    def __init__(self, world_size, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        self._lib.sfm_comm_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        check(self._lib.sfm_comm_create(int(world_size), int(rank), bytes(unique_id), ctypes.byref(self._h)))
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def close(self):
+        if self._h:
+            self._lib.sfm_comm_destroy.argtypes = [ctypes.c_void_p]
+            check(self._lib.sfm_comm_destroy(self._h))
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def pnp_ransac_evaluate(uv_pix, pts_h, intrinsic, samples, threshold):
     """Every six-point hypothesis: (rot (n_hyp,3,3), loc (n_hyp,3), inlier counts under (R, C), inlier counts under (R, -C))."""
     uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic)
@@ -518,6 +553,13 @@ class BaProblem:
     def flush(self):
         """Complete the back substitution ``solve_update`` may have left to the next linearisation (sfm_ba_flush)."""
         check(self._lib.sfm_ba_flush(self._h))
+
+    def set_comm(self, comm):
+        """Attach a library-owned RCCL communicator (``Comm``) or detach it (None): ``iterate`` then all-reduces the
+        packed [S | rhs] buffer itself, once per iteration, on the problem's stream (sfm_ba_set_comm)."""
+        self._lib.sfm_ba_set_comm.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        check(self._lib.sfm_ba_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm                      # keep it alive as long as it is attached
 
     def get_stats(self, max_iters=256):
         """Per-iteration cost sum |b - f|^2 (normalised image coordinates) at the start of every iteration run since

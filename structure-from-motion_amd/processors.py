@@ -335,7 +335,11 @@ class HipBaMixin:
     plus whatever pose or old point the caller changed since the last write-back.  (The reference re-derives every
     quaternion from ``view.rot`` at the start of a call, ba:285-288; for views whose ``rot`` / ``loc`` still hold what the
     last call wrote, that round trip q -> R(q) -> q(R) runs on the device, ``sfm_ba_rederive_quaternions``.)  If anything was REMOVED (an observation,
-    a point, a view) or an existing key / intrinsic changed, the problem is rebuilt from scratch.
+    a point, a view), an existing key -> point entry of a track table changed, or a view's key LIST or intrinsic matrix was
+    replaced, the problem is rebuilt from scratch.  The pixel coordinates of a key are read ONCE, when its view's key list is
+    first seen (``observations.KeyCache``): ``view.key_pts`` is treated as immutable -- the reference's front end never edits a
+    ``cv2.KeyPoint`` after detection (view_processor.py) -- and a caller that does edit ``key_pts[i].pt`` in place has to call
+    ``ba_release()`` (or hand the view a new list) for the edit to reach the device.
     ``ba_upload_bytes`` reports the PCIe bytes spent so far; ``ba_release()`` frees the device copy."""
 
     ba_quirk_flags = native.QUIRKS_REFERENCE

@@ -21,20 +21,19 @@ import numpy as np
 def det_branch_fires(key_2d_pts_6_in_cam_coord, tri_3d_pts_6):
     """True when campose_processor.py:629 sees ``det(rot) < 0`` for this six-point sample: the reference's own
     expressions (campose:585-626) on the reference's own inputs, evaluated by the host's LAPACK."""
-    p2d, p3d = key_2d_pts_6_in_cam_coord, tri_3d_pts_6
+    p2d, p3d = np.asarray(key_2d_pts_6_in_cam_coord), np.asarray(tri_3d_pts_6)
+    # campose:588-611, the same products element by element (the fourth entry of a point is taken to be 1 there)
+    x, y, z = p2d[0], p2d[1], p2d[2]
+    pts = p3d[0:3].T                          # (6, 3)
     w = np.zeros((12, 12))
-    for k in range(6):                      # campose:588-611 (the fourth entry of a point is taken to be 1 there)
-        x, y, z = p2d[0][k], p2d[1][k], p2d[2][k]
-        pt = (p3d[0][k], p3d[1][k], p3d[2][k])
-        for c in range(3):
-            w[2 * k][c] = z * pt[c]
-            w[2 * k + 1][4 + c] = z * pt[c]
-            w[2 * k][8 + c] = -x * pt[c]
-            w[2 * k + 1][8 + c] = -y * pt[c]
-        w[2 * k][3] = z
-        w[2 * k + 1][7] = z
-        w[2 * k][11] = -x
-        w[2 * k + 1][11] = -y
+    w[0::2, 0:3] = z[:, None] * pts
+    w[0::2, 3] = z
+    w[0::2, 8:11] = -x[:, None] * pts
+    w[0::2, 11] = -x
+    w[1::2, 4:7] = z[:, None] * pts
+    w[1::2, 7] = z
+    w[1::2, 8:11] = -y[:, None] * pts
+    w[1::2, 11] = -y
     _u, _s, vh = np.linalg.svd(w)
     cam_mat = np.reshape(vh.transpose()[:, -1], (3, 4))
     uu, _ss, vvh = np.linalg.svd(cam_mat[:, 0:3])
@@ -55,6 +54,8 @@ def reference_winner(counts, counts_neg, fires):
     for h in order.tolist():
         if upper[h] < best_cnt or upper[h] == 0:
             break
+        if upper[h] == best_cnt and best_h >= 0 and h > best_h:
+            break                                                     # could only tie, and ties go to the earlier hypothesis
         if counts[h] == counts_neg[h]:
             fired, score = None, int(counts[h])                       # the decision does not matter for the score
         else:

@@ -150,14 +150,23 @@ class HipShardEngine:
         self.prob.flush()
 
     def iterate_local(self, lam, iters, quirks=native.QUIRKS_REFERENCE):
-        """``iters`` complete iterations with NO exchange step (one rank owns every point): one C-ABI call
-        (``sfm_ba_iterate``), the path the drop-in classes take."""
+        """``iters`` complete iterations in ONE C-ABI call (``sfm_ba_iterate``): with no exchange step when one rank owns
+        every point (the path the drop-in classes take), or -- after ``attach_comm`` -- with the library's own RCCL
+        all-reduce of [S | rhs] between the partial reduce and the replicated solve of every iteration."""
         self.prob.iterate(lam, iters, quirks)
+
+    def attach_comm(self, comm):
+        """Hand the exchange step to the library (``native.Comm``; None detaches): no Python between the iterations."""
+        self.prob.set_comm(comm)
+        self.comm = comm
 
     def get_state(self):
         return self.prob.get_state()
 
     def close(self):
+        if getattr(self, "comm", None) is not None:
+            self.prob.set_comm(None)
+            self.comm = None
         self.prob.bind_reduced_buffer(0, 0)
         self.prob.close()
 

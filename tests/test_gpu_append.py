@@ -241,3 +241,50 @@ def test_pool_red_zone_mode_follows_the_environment(hip):
     library honours the variable."""
     import os
     assert hip.pool_redzone_active() == (os.environ.get("SFM_POOL_REDZONE", "0") == "1")
+
+
+@pytest.mark.parametrize("shape", [(50, 4000, 0.6), (9, 800, 1.0), (60, 1500, 0.2)])
+def test_library_owned_communicator_runs_the_sharded_loop_in_one_call(hip, sfm, oracle, shape):
+    """the library owns the RCCL communicator (sfm_comm_unique_id / sfm_comm_create) and,
+    once it is attached (sfm_ba_set_comm), sfm_ba_iterate issues the all-reduce of [S | rhs] itself between the partial
+    reduce and the replicated solve -- K iterations in ONE C call.  One GPU here, so a communicator of ONE rank (RCCL
+    refuses two ranks on a device): the collective runs, its sum is the rank's own system, and the result must equal the
+    loop without a communicator and the oracle.  Through the engine (caller-bound reduced buffer) and the bare problem."""
+    import torch
+    n_cams, n_pts, vis = shape
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=41)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    ocams, opts = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 3)
+        cams0, pts0 = prob.get_state()
+    comm = hip.Comm(1, 0, hip.comm_unique_id())
+    try:
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_comm(comm)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            cams1, pts1 = prob.get_state()
+            prob.set_comm(None)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            cams2, pts2 = prob.get_state()
+        eng = sfm.sharding.HipShardEngine(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn, torch.device("cuda", 0))
+        try:
+            eng.attach_comm(comm)
+            eng.set_state(sc.cams_init, sc.pts_init)
+            sfm.sharding.ShardedBa(eng, None, 1).iterate(5.0, 3)
+            cams3, pts3 = eng.get_state()
+        finally:
+            eng.close()
+    finally:
+        comm.close()
+    scale_c, scale_p = np.max(np.abs(ocams)), np.max(np.abs(opts))
+    for cams, pts in ((cams1, pts1), (cams2, pts2), (cams3, pts3)):
+        assert np.max(np.abs(cams - ocams)) < 1e-9 * scale_c and np.max(np.abs(pts - opts)) < 1e-9 * scale_p
+        assert np.max(np.abs(cams - cams0)) < 1e-11 * scale_c and np.max(np.abs(pts - pts0)) < 1e-11 * scale_p
+    with pytest.raises(ValueError):
+        hip.Comm(1, 0, b"short")
+    with pytest.raises(ValueError):
+        hip.Comm(2, 5, hip.comm_unique_id())          # rank outside the world: SFM_E_SHAPE

@@ -3,7 +3,7 @@
 # of box acquisition, so everything rides in one).  Usage (from the repo root on the GPU box):
 #   bash tools/gpu_round.sh [tag]
 # Stops at the first step that is killed / timed out (rc >= 124); ordinary test failures do not stop it.
-tag=${1:-r3}
+tag=${1:-r4}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp

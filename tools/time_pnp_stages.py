@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, ".")
 sfm = importlib.import_module("structure-from-motion_amd"); native = sfm.native; native.init(0)
 import bench
-for n in (200, 400, 600, 1000, 1112, 2224, 3336, 5000):
+for n in (200, 400, 600, 1000, 1112, 2224, 3000, 3336, 5000, 9601):
     off, uvp, xs, ks, r0, c0 = bench.pnp_batch(sfm, 1, n, seed=3)
     random.seed(1)
     samples = [random.sample(range(n), 6) for _ in range(300)]
