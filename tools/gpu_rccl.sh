@@ -9,6 +9,13 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 tr() { port=$1; shift; timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port "$port" bench.py --gpus 1 "$@"; }
 tr 29541 --steps 100 --warmup 10 --no-cpu-baseline > "$out/torchrun_c3.log" 2>&1; echo "c3 rc=$?" | tee -a "$out/steps.log"
 grep '^{' "$out/torchrun_c3.log" > "$out/bench_torchrun_1rank_rccl_c3.json"
+# round 4: the library's own communicator inside sfm_ba_iterate (one C-ABI call for all K iterations), same box, interleaved
+for rep in 1 2; do
+  tr 2955$rep --steps 100 --warmup 10 --no-cpu-baseline --collective library > "$out/torchrun_c3_library$rep.log" 2>&1; echo "c3 library $rep rc=$?" | tee -a "$out/steps.log"
+  grep '^{' "$out/torchrun_c3_library$rep.log" > "$out/bench_torchrun_1rank_library_c3_$rep.json"
+  tr 2956$rep --steps 100 --warmup 10 --no-cpu-baseline > "$out/torchrun_c3_allreduce$rep.log" 2>&1; echo "c3 allreduce $rep rc=$?" | tee -a "$out/steps.log"
+  grep '^{' "$out/torchrun_c3_allreduce$rep.log" > "$out/bench_torchrun_1rank_rccl_c3_$rep.json"
+done
 tr 29542 --config C4 --pts 12500 --steps 20 --warmup 3 --no-cpu-baseline > "$out/torchrun_c4share.log" 2>&1; echo "c4share rc=$?" | tee -a "$out/steps.log"
 grep '^{' "$out/torchrun_c4share.log" > "$out/bench_torchrun_1rank_rccl_c4share.json"
 tr 29543 --config TRI --steps 20 --warmup 2 --no-cpu-baseline > "$out/torchrun_tri.log" 2>&1; echo "tri rc=$?" | tee -a "$out/steps.log"
