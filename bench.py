@@ -331,6 +331,16 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
     engine.prob.set_option(native.OPT_SCHUR, schur_mode)
     if args.debug:
         engine.prob.set_option(native.OPT_DEBUG, args.debug)
+    if collective == "auto":
+        # N > 1: the library's own communicator when every rank can have one (measured at one rank: 3 607-3 614 it/s against
+        # 3 491-3 511 with torch.distributed.all_reduce between two C-ABI calls per iteration, profiles/r4/bench_torchrun_1rank_*);
+        # all ranks agree before any of them enters ncclCommInitRank
+        collective = "allreduce"
+        if use_dist and world > 1 and not rehearsal:
+            ok = torch.tensor([1.0 if native.comm_available() else 0.0], dtype=torch.float64, device=ctx.coll_device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 1.0:
+                collective = "library"
     if collective == "library":
         # the library owns the communicator (sfm_comm_create: ncclCommInitRank on this rank's GPU) and issues the all-reduce
         # itself inside sfm_ba_iterate: K iterations = ONE C-ABI call per rank, no Python between them.  The 128-byte id
@@ -432,7 +442,7 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
                                     args.config, scene.n_cams, pts_per_rank, 100 * cfg["visibility"])),
             "observations_per_rank": int(cam_l.shape[0]), "points_total": int(scene.n_pts),
             "parallelism": "points sharded x%d, cameras replicated, %s of [S|rhs] per iteration" % (world, collective) if world > 1 else "single GPU",
-            "collective_backend": ctx.backend,
+            "collective_backend": ctx.backend, "collective": collective,
             "schur": args.schur, **({"debug_bits": args.debug} if args.debug else {})},
         "rmse_px": {"initial": rmse_init, "after_3_iterations": rmse_gpu3, "after_timed_run": rmse_end},
     }
@@ -535,12 +545,13 @@ def run_ba(args, ctx):
     primary_strong = c4_fixed or args.scaling == "strong"
     collective = args.collective
     out, extra = ba_measure(args, ctx, sfm, primary_strong, True, collective)
-    if ctx.use_dist and world > 1 and out.get("max_camera_deviation_across_ranks", 0.0) != 0.0 and collective == "allreduce":
+    collective = out["config"].get("collective", collective)
+    if ctx.use_dist and world > 1 and out.get("max_camera_deviation_across_ranks", 0.0) != 0.0 and collective in ("allreduce", "library"):
         # replicas drifted: the all-reduce did not hand every rank the same bytes.  Not a lost run: record it, repeat the
         # measurement with the reduce + broadcast exchange (identical bytes by construction) and report THAT as `value`
         drift = {"max_camera_deviation_across_ranks": out["max_camera_deviation_across_ranks"], "value_with_drift": out["value"],
                  "ms_per_step_with_drift": out["ms_per_step"],
-                 "note": "torch.distributed.all_reduce left the ranks with different [S | rhs] bits; re-measured with reduce(dst=0) + broadcast"}
+                 "note": "the all-reduce (%s) left the ranks with different [S | rhs] bits; re-measured with reduce(dst=0) + broadcast" % collective}
         extra.engine.close()
         collective = "reduce_broadcast"
         out, extra = ba_measure(args, ctx, sfm, primary_strong, True, collective)
@@ -1020,8 +1031,8 @@ def main():
                     help="C3 with N > 1: which figure is `value` (auto = weak: 20 000 points per rank; strong = the fixed 50 x 20k scene split "
                          "over the ranks); the other one is timed as well and reported next to it")
     ap.add_argument("--single-scaling", action="store_true", help="C3 with N > 1: time only the figure --scaling names")
-    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "reduce_broadcast", "library"],
-                    help="the per-iteration exchange of [S | rhs]: allreduce = torch.distributed (RCCL) between two C-ABI calls per iteration; "
+    ap.add_argument("--collective", default="auto", choices=["auto", "allreduce", "reduce_broadcast", "library"],
+                    help="the per-iteration exchange of [S | rhs] (auto = library for N > 1 when every rank can load RCCL, else allreduce): allreduce = torch.distributed (RCCL) between two C-ABI calls per iteration; "
                          "reduce_broadcast = the repair the bench falls back to by itself when the ranks' cameras drift apart under allreduce; "
                          "library = the library's own RCCL communicator inside sfm_ba_iterate (one C-ABI call for all K iterations)")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "TRI", "PNP", "C5"])

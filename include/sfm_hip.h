@@ -352,6 +352,9 @@ int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_do
  * / librccl.so: a process that already carries torch's copy gets that one); the library has no link-time dependency on it.
  * The reference has no distributed code; the algebra is ba_processor.py:376-406 (sums over points). */
 typedef struct sfm_comm sfm_comm;
+/* SFM_OK when RCCL can be loaded in this process (so that all ranks can agree on the library path BEFORE any of them
+ * enters ncclCommInitRank), SFM_E_RCCL otherwise. */
+int sfm_comm_available(void);
 int sfm_comm_unique_id(char id_out[128]);
 int sfm_comm_create(int world_size, int rank, const char id[128], sfm_comm** out);
 int sfm_comm_destroy(sfm_comm* comm);

@@ -87,6 +87,11 @@ using namespace sfm;
 
 extern "C" {
 
+int sfm_comm_available(void) {
+  SFM_TRY(ensure_init());
+  return load_rccl();
+}
+
 int sfm_comm_unique_id(char id_out[128]) {
   SFM_TRY(ensure_init());
   if (id_out == nullptr) { set_error("sfm_comm_unique_id: id_out is null"); return SFM_E_SHAPE; }

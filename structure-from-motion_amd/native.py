@@ -29,7 +29,7 @@ EXPORTS = (
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_pnp_linear_ransac", "sfm_pnp_six_point_hypotheses", "sfm_pnp_ransac_evaluate", "sfm_pnp_inlier_mask",
-    "sfm_comm_unique_id", "sfm_comm_create", "sfm_comm_destroy", "sfm_ba_set_comm",
+    "sfm_comm_available", "sfm_comm_unique_id", "sfm_comm_create", "sfm_comm_destroy", "sfm_ba_set_comm",
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
     "sfm_ba_solve", "sfm_ba_create", "sfm_ba_destroy", "sfm_ba_set_option", "sfm_ba_set_state",
@@ -311,6 +311,11 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
                                     float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
                                     ctypes.byref(best)))
     return rot, loc.reshape(3, 1), np.flatnonzero(mask).tolist(), best.value
+
+
+def comm_available():
+    """True when the library can load RCCL in this process (sfm_comm_available)."""
+    return load().sfm_comm_available() == OK
 
 
 def comm_unique_id():
