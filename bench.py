@@ -310,6 +310,15 @@ def make_all_reduce(ctx, mode):
     return lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def close_engine(engine):
+    """Release a shard engine and, if the bench created one for it, the library-owned communicator."""
+    comm = getattr(engine, "owned_comm", None)
+    engine.close()
+    if comm is not None:
+        comm.close()
+        engine.owned_comm = None
+
+
 def ba_measure(args, ctx, sfm, strong, full, collective):
     """One BA workload on this process group: scene, shard, (parity leg), warm-up, pre-roll, R timed regions of EXACTLY
     K steps each.  `strong`: the scene is the config's own (points split over the ranks); otherwise every rank owns
@@ -352,6 +361,7 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
             dist.broadcast_object_list(ident, src=0)
         comm = native.Comm(world, rank, ident[0])
         engine.attach_comm(comm)
+        engine.owned_comm = comm             # closed with the engine (close_engine below)
         ba = sfm.sharding.ShardedBa(engine, None, world)
     else:
         ba = sfm.sharding.ShardedBa(engine, make_all_reduce(ctx, collective), world)
@@ -472,7 +482,7 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
     extra = Holder()
     extra.scene, extra.uvn, extra.engine, extra.cams3, extra.pts3, extra.rmse_gpu3 = scene, uvn, engine, cams3, pts3, rmse_gpu3
     if not full:
-        engine.close()
+        close_engine(engine)
         return out, extra
 
     out["kernel_ms"] = breakdown
@@ -552,7 +562,7 @@ def run_ba(args, ctx):
         drift = {"max_camera_deviation_across_ranks": out["max_camera_deviation_across_ranks"], "value_with_drift": out["value"],
                  "ms_per_step_with_drift": out["ms_per_step"],
                  "note": "the all-reduce (%s) left the ranks with different [S | rhs] bits; re-measured with reduce(dst=0) + broadcast" % collective}
-        extra.engine.close()
+        close_engine(extra.engine)
         collective = "reduce_broadcast"
         out, extra = ba_measure(args, ctx, sfm, primary_strong, True, collective)
         out["replica_drift"] = drift
@@ -568,7 +578,7 @@ def run_ba(args, ctx):
 
     # ---- CPU baseline (rank 0, N = 1): the NumPy block-sparse oracle on the same scene --------------------------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        engine.close()
+        close_engine(engine)
         # (ii) cpu_ref_sparse, default BLAS threads: median of three runs of 3 iterations (the state after 3 feeds the parity figures)
         leg = cpu_leg("sparse", args.config, 3, 3, args.pts)
         med = float(np.median(leg["seconds"]))
@@ -609,7 +619,7 @@ def run_ba(args, ctx):
         out["drop_in_path_small"] = drop_in_path(sfm, sfm.scenes.make_scene(6, 1260, 1.0, seed=0))
 
     if world > 1 or args.no_cpu_baseline:
-        engine.close()
+        close_engine(engine)
     finish(ctx, out)
 
 

@@ -192,6 +192,7 @@ int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirk
 bool ba_can_fuse(const sfm_ba_problem* p);
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras
 int comm_all_reduce_f64(sfm_comm* comm, double* buf, size_t count, hipStream_t s);      // sfm_comm.hip
+int comm_attach(sfm_comm* comm, int delta);      // a problem takes (+1) / gives back (-1) its hold on a communicator
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);
 void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out);
 }  // namespace sfm

@@ -292,6 +292,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   if (p == nullptr) return SFM_OK;
   if (p->magic != kBaMagic) { set_error("sfm_ba_destroy: invalid handle"); return SFM_E_HANDLE; }
   if (ctx().inited && p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->comm) { (void)comm_attach(p->comm, -1); p->comm = nullptr; }
   ba_graph_drop(p);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
@@ -646,6 +647,8 @@ int sfm_ba_set_comm(sfm_ba_problem* p, sfm_comm* comm) {
   SFM_TRY(check_problem(p));
   SFM_TRY(ba_flush(p));
   ba_graph_drop(p);          // a captured iteration body has no collective in it
+  SFM_TRY(comm_attach(comm, +1));
+  if (p->comm) { SFM_HIP(hipStreamSynchronize(p->stream)); (void)comm_attach(p->comm, -1); }      // no collective of the old one in flight
   p->comm = comm;
   return SFM_OK;
 }

@@ -18,6 +18,7 @@ struct sfm_comm {
   unsigned magic;
   void* nccl;        // ncclComm_t
   int world, rank;
+  int attached;      // problems that hold it (sfm_ba_set_comm): it cannot be destroyed under them
 };
 
 namespace sfm {
@@ -74,6 +75,13 @@ int rccl_fail(int code, const char* what) {
 
 }  // namespace
 
+int comm_attach(sfm_comm* comm, int delta) {
+  if (comm == nullptr) return SFM_OK;
+  if (comm->magic != kCommMagic) { set_error("invalid communicator handle"); return SFM_E_HANDLE; }
+  comm->attached += delta;
+  return SFM_OK;
+}
+
 int comm_all_reduce_f64(sfm_comm* comm, double* buf, size_t count, hipStream_t s) {
   if (comm == nullptr || comm->magic != kCommMagic) { set_error("invalid communicator handle"); return SFM_E_HANDLE; }
   const int rc = rccl().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, comm->nccl, s);
@@ -118,13 +126,17 @@ int sfm_comm_create(int world_size, int rank, const char id[128], sfm_comm** out
   void* nccl = nullptr;
   const int rc = rccl().CommInitRank(&nccl, world_size, uid, rank);
   if (rc != 0) return rccl_fail(rc, "ncclCommInitRank");
-  *out = new sfm_comm{kCommMagic, nccl, world_size, rank};
+  *out = new sfm_comm{kCommMagic, nccl, world_size, rank, 0};
   return SFM_OK;
 }
 
 int sfm_comm_destroy(sfm_comm* comm) {
   if (comm == nullptr) return SFM_OK;
   if (comm->magic != kCommMagic) { set_error("sfm_comm_destroy: invalid handle"); return SFM_E_HANDLE; }
+  if (comm->attached > 0) {
+    set_error("sfm_comm_destroy: %d problem(s) still hold this communicator (sfm_ba_set_comm(p, NULL) or sfm_ba_destroy first)", comm->attached);
+    return SFM_E_HANDLE;
+  }
   if (ctx().inited) (void)hipDeviceSynchronize();
   const int rc = rccl().CommDestroy(comm->nccl);
   comm->magic = 0;

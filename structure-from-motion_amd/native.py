@@ -342,7 +342,7 @@ class Comm:
     def close(self):
         if self._h:
             self._lib.sfm_comm_destroy.argtypes = [ctypes.c_void_p]
-            check(self._lib.sfm_comm_destroy(self._h))
+            check(self._lib.sfm_comm_destroy(self._h))      # refused (SfmHipError) while a problem still holds it
             self._h = ctypes.c_void_p()
 
     def __enter__(self):

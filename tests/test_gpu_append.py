@@ -273,6 +273,8 @@ def test_library_owned_communicator_runs_the_sharded_loop_in_one_call(hip, sfm, 
         eng = sfm.sharding.HipShardEngine(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn, torch.device("cuda", 0))
         try:
             eng.attach_comm(comm)
+            with pytest.raises(hip.SfmHipError, match="still hold"):
+                comm.close()                               # a communicator cannot be destroyed under a problem that holds it
             eng.set_state(sc.cams_init, sc.pts_init)
             sfm.sharding.ShardedBa(eng, None, 1).iterate(5.0, 3)
             cams3, pts3 = eng.get_state()
