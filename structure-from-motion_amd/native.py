@@ -295,9 +295,9 @@ def pnp_nonlinear(uv_pix, pts_h, intrinsic, rot0, loc0, lam, iters, quirks=QUIRK
     return rot, loc.reshape(3, 1)
 
 
-def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
+def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold, as_array=False):
     """Evaluate six-point DLT hypotheses (samples: (n_hyp, 6) indices drawn by the caller) and return
-    (rot (3,3), loc (3,1), inlier index list, best hypothesis index or -1)."""
+    (rot (3,3), loc (3,1), inlier index list (or int array with ``as_array``), best hypothesis index or -1)."""
     uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic)
     samples = i32(samples).reshape(-1, 6)
     n, n_hyp = uv_pix.shape[1], samples.shape[0]
@@ -310,7 +310,8 @@ def pnp_linear_ransac(uv_pix, pts_h, intrinsic, samples, threshold):
     check(lib.sfm_pnp_linear_ransac(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples),
                                     float(threshold), dptr(rot), dptr(loc), iptr(mask), ctypes.byref(cnt),
                                     ctypes.byref(best)))
-    return rot, loc.reshape(3, 1), np.flatnonzero(mask).tolist(), best.value
+    idx = np.flatnonzero(mask)
+    return rot, loc.reshape(3, 1), (idx if as_array else idx.tolist()), best.value
 
 
 def comm_available():
@@ -366,8 +367,8 @@ def pnp_ransac_evaluate(uv_pix, pts_h, intrinsic, samples, threshold):
     return rot, loc, cnt, cnt_neg
 
 
-def pnp_inlier_mask(uv_pix, pts_h, intrinsic, rot, loc, threshold):
-    """Inlier index list of one pose (pixel reprojection error below `threshold`, campose_processor.py:544-554)."""
+def pnp_inlier_mask(uv_pix, pts_h, intrinsic, rot, loc, threshold, as_array=False):
+    """Inlier index list (or int array) of one pose (pixel reprojection error below `threshold`, campose_processor.py:544-554)."""
     uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic); rot = f64(rot); loc = f64(loc).reshape(3)
     n = uv_pix.shape[1]
     mask = np.empty(n, dtype=np.int32)
@@ -376,7 +377,8 @@ def pnp_inlier_mask(uv_pix, pts_h, intrinsic, rot, loc, threshold):
     lib.sfm_pnp_inlier_mask.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, _ip, _ip]
     check(lib.sfm_pnp_inlier_mask(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), dptr(rot), dptr(loc), float(threshold),
                                   iptr(mask), ctypes.byref(cnt)))
-    return np.flatnonzero(mask).tolist()
+    idx = np.flatnonzero(mask)
+    return idx if as_array else idx.tolist()
 
 
 def pnp_six_point_hypotheses(uv_pix, pts_h, intrinsic, samples, threshold):
