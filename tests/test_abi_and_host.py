@@ -232,6 +232,19 @@ int main(void) {
   if (rc == SFM_OK && (R[0] != 1.0 || R[4] != 1.0 || R[8] != 1.0 || st != SFM_OK)) return 4;
   sfm_ba_problem* p = 0;
   if (sfm_ba_destroy(p) != SFM_OK) return 5;         /* destroying a null handle is a no-op */
+  /* the communicator API from plain C (round 4): without a device every call reports SFM_E_NO_DEVICE, with one
+     sfm_comm_available says whether RCCL can be loaded; a one-rank communicator is then created and destroyed */
+  char id[128];
+  sfm_comm* comm = 0;
+  int ra = sfm_comm_available();
+  if (rc == SFM_E_NO_DEVICE && ra != SFM_E_NO_DEVICE) return 6;
+  if (rc == SFM_OK && ra == SFM_OK) {
+    if (sfm_comm_unique_id(id) != SFM_OK) return 7;
+    if (sfm_comm_create(1, 0, id, &comm) != SFM_OK || comm == 0) return 8;
+    sfm_comm* bad = 0;
+    if (sfm_comm_create(2, 7, id, &bad) != SFM_E_SHAPE || bad != 0) return 9;      /* rank outside the world */
+  }
+  if (sfm_comm_destroy(comm) != SFM_OK) return 10;   /* null is a no-op as well */
   printf("abi ok rc=%d\n", rc);
   return 0;
 }
