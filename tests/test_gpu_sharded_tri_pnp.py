@@ -89,6 +89,25 @@ def test_pnp_split_views_sharded_equal_unsharded_and_match_the_oracle(hip, sfm, 
         assert np.all(np.isfinite(got_r)) and abs(np.linalg.det(got_r) - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_pnp_split_random_sizes_and_quirks_match_the_oracle(hip, sfm, oracle, seed):
+    """Random view sizes around the class boundaries and the slice boundaries of the split class (3 000 = 3 slices of 1 000;
+    k x 1 024 +- 1; a last slice of one point), random quirk combination, through the batched entry point -- against the
+    oracle's per-point loop (campose_processor.py:378-422)."""
+    rng = np.random.default_rng(100 + seed)
+    edge = [2999, 3000, 3001, 3071, 3072, 3073, 4096, 4097, 5121, 6145, 10241]
+    sizes = [int(rng.choice(edge)), int(rng.integers(3000, 9000)), int(rng.integers(1, 1200))]
+    quirks = int(rng.integers(0, 4))
+    iters = int(rng.integers(1, 4))
+    offsets, uvp, xs, ks, r0, c0 = _pnp_case(sfm, sizes, seed=200 + seed)
+    rot, loc, st = hip.pnp_nonlinear_batch(offsets, uvp, xs, ks, r0, c0, 5.0, iters, quirks)
+    assert not st.any()
+    for v, n in enumerate(sizes):
+        a, b = int(offsets[v]), int(offsets[v + 1])
+        r_or, c_or = oracle.nonlinear_pnp(uvp[:, a:b], xs[:, a:b], ks[v], r0[v], c0[v].reshape(3, 1), 5.0, iters, quirks=quirks)
+        assert rel(rot[v], r_or) < 1e-9 and rel(loc[v], c_or.reshape(3)) < 1e-9, (sizes, quirks, iters, v)
+
+
 def test_device_pointer_entry_points_match_host_entry_points(hip, sfm):
     """sfm_tri_nonlinear_dev / sfm_tri_linear_dev / sfm_triangulate_dev / sfm_pnp_nonlinear_batch_dev: torch tensors in
     HBM, the caller's stream, no implicit synchronisation -- the same kernels as the host-pointer calls, bit for bit."""
