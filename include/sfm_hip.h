@@ -212,6 +212,23 @@ int sfm_pnp_ransac_evaluate(int n, const double* uv_pix /*[3][n]*/, const double
 int sfm_pnp_inlier_mask(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
                         const double R[9], const double C[3], double threshold, int* inlier_mask /*[n]*/, int* n_inliers);
 
+/* CamposeProcessor.estimate_cam_pose_pnp (campose_processor.py:192-246) as two calls around the host's choice of the winner,
+ * with the view's keys and points RESIDENT on the device in between: sfm_pnp_ransac_begin = sfm_pnp_ransac_evaluate + a
+ * session; sfm_pnp_ransac_finish(session, R, C of the chosen hypothesis, ...) = the inlier mask of that pose, the inlier
+ * columns compacted on the device in ascending order (campose:236-237) and `iters` nonlinear iterations on them
+ * (campose:239) -- the result of sfm_pnp_inlier_mask followed by sfm_pnp_nonlinear on the gathered columns, bit for bit,
+ * with one upload instead of three.  finish releases the session (also when it fails); sfm_pnp_session_destroy releases
+ * one that is never finished. */
+typedef struct sfm_pnp_session sfm_pnp_session;
+int sfm_pnp_ransac_begin(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],
+                         int n_hyp, const int* samples /*[n_hyp][6]*/, double threshold,
+                         double* R_out /*[n_hyp][9]*/, double* C_out /*[n_hyp][3]*/, int* counts /*[n_hyp]*/,
+                         int* counts_neg /*[n_hyp]*/, sfm_pnp_session** out);
+int sfm_pnp_ransac_finish(sfm_pnp_session* session, const double R[9], const double C[3], double threshold,
+                          double lambda, int iters, int quirks, int* inlier_mask /*[n]*/, int* n_inliers,
+                          double R_out[9], double C_out[3]);
+int sfm_pnp_session_destroy(sfm_pnp_session* session);
+
 /* Parity hook: every hypothesis of the RANSAC above -- pose and inlier count of each six-point sample
  * (campose_processor.py:524-560 loop body, 565-633). */
 int sfm_pnp_six_point_hypotheses(int n, const double* uv_pix /*[3][n]*/, const double* X /*[4][n]*/, const double K[9],

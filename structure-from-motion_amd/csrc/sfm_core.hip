@@ -991,6 +991,44 @@ __global__ void pnp_inlier_mask_kernel(int n, const double* __restrict__ proj, c
   mask[i] = pnp_is_inlier(P, uv_pix, X, n, i, threshold) ? 1 : 0;
 }
 
+// Stable compaction of the inlier columns (campose_processor.py:236-237: key_2d_pts[:, inlier_indices], tri_3d_pts[:, inlier_indices]
+// with the indices ascending): one workgroup scans the mask, then every inlier column goes to its rank.  The compacted arrays
+// keep the row pitch n of the originals (only the first m columns are written); offsets = {0, m} for the nonlinear kernel.
+__global__ __launch_bounds__(1024) void pnp_mask_scan_kernel(int n, const int* __restrict__ mask, int* __restrict__ pos, int* __restrict__ offsets) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int a = i < n ? (mask[i] != 0) : 0;
+    int sa = a;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(sa, off, 64); if (lane >= off) sa += t; }
+    if (lane == 63) wsum[wave] = sa;
+    __syncthreads();
+    int o = carry;
+    for (int w = 0; w < wave; ++w) o += wsum[w];
+    if (i < n) pos[i] = o + sa - a;
+    __syncthreads();
+    if (tid == 1023) carry = o + sa;
+    __syncthreads();
+  }
+  if (tid == 0) { offsets[0] = 0; offsets[1] = carry; }
+}
+
+__global__ void pnp_compact_kernel(int n, const int* __restrict__ mask, const int* __restrict__ pos, const double* __restrict__ uv_pix,
+                                   const double* __restrict__ X, double* __restrict__ uv_c, double* __restrict__ X_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || mask[i] == 0) return;
+  const int q = pos[i];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) uv_c[(size_t)r * n + q] = uv_pix[(size_t)r * n + i];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) X_c[(size_t)r * n + q] = X[(size_t)r * n + i];
+}
+
 // Columns [4][n] (X, Y, Z, 1) of the points index[0..n) of SoA point arrays (e.g. a resident BA problem's, sfm_ba_points_ptr):
 // what the per-view PnP of the incremental loop consumes (ba_processor.py:184-191), built without a host round trip.
 __global__ void gather_points_kernel(int n, const int* __restrict__ index, const double* __restrict__ px,
@@ -1502,6 +1540,118 @@ int sfm_pnp_inlier_mask(int n, const double* uv_pix, const double* X, const doub
   for (int i = 0; i < n; ++i) cnt += inlier_mask[i] != 0;
   if (n_inliers) *n_inliers = cnt;
   return SFM_OK;
+}
+
+// ---- estimate_cam_pose_pnp as two calls around the host's decision (quirk Q13) with the view RESIDENT in between ----------------
+// campose_processor.py:192-246 = RANSAC (which hypothesis wins is the host's call: q13.py) -> the winner's inliers -> 300
+// nonlinear iterations on them.  sfm_pnp_ransac_begin = sfm_pnp_ransac_evaluate that keeps the keys and points on the
+// device; sfm_pnp_ransac_finish scores the chosen pose, compacts the inlier columns on the device (ascending, as the
+// reference's list indexes them) and refines on them: the keys and points cross PCIe once instead of three times and the
+// host never gathers columns.
+struct sfm_pnp_session {
+  unsigned magic;
+  int n;
+  double *dUV, *dX, *dK;
+};
+namespace sfm { constexpr unsigned kPnpSessionMagic = 0x5F3B5E55u; }
+
+int sfm_pnp_session_destroy(sfm_pnp_session* ses) {
+  if (ses == nullptr) return SFM_OK;
+  if (ses->magic != kPnpSessionMagic) { set_error("sfm_pnp_session_destroy: invalid handle"); return SFM_E_HANDLE; }
+  if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+  pool_free(ses->dUV); pool_free(ses->dX); pool_free(ses->dK);
+  ses->magic = 0;
+  delete ses;
+  return SFM_OK;
+}
+
+int sfm_pnp_ransac_begin(int n, const double* uv_pix, const double* X, const double K[9], int n_hyp, const int* samples,
+                         double threshold, double* R_out, double* C_out, int* counts, int* counts_neg, sfm_pnp_session** out) {
+  SFM_TRY(ensure_init());
+  if (out == nullptr) { set_error("sfm_pnp_ransac_begin: out is null"); return SFM_E_SHAPE; }
+  *out = nullptr;
+  if (n < 6 || n_hyp < 1) { set_error("sfm_pnp_ransac_begin: need n >= 6 points and n_hyp >= 1 (n=%d n_hyp=%d)", n, n_hyp); return SFM_E_SHAPE; }
+  for (int i = 0; i < 6 * n_hyp; ++i)
+    if (samples[i] < 0 || samples[i] >= n) { set_error("sfm_pnp_ransac_begin: sample index %d out of range", samples[i]); return SFM_E_SHAPE; }
+  hipStream_t s = ctx().stream;
+  sfm_pnp_session* ses = new sfm_pnp_session{kPnpSessionMagic, n, nullptr, nullptr, nullptr};
+  auto fail = [&](int st) { (void)sfm_pnp_session_destroy(ses); return st; };
+  if (pool_alloc(reinterpret_cast<void**>(&ses->dUV), sizeof(double) * 3 * (size_t)n) != hipSuccess ||
+      pool_alloc(reinterpret_cast<void**>(&ses->dX), sizeof(double) * 4 * (size_t)n) != hipSuccess ||
+      pool_alloc(reinterpret_cast<void**>(&ses->dK), sizeof(double) * 9) != hipSuccess) {
+    set_error("sfm_pnp_ransac_begin: out of device memory");
+    return fail(SFM_E_HIP);
+  }
+  auto run = [&]() -> int {
+    SFM_HIP(hipMemcpyAsync(ses->dUV, uv_pix, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    SFM_HIP(hipMemcpyAsync(ses->dX, X, sizeof(double) * 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    SFM_HIP(hipMemcpyAsync(ses->dK, K, sizeof(double) * 9, hipMemcpyHostToDevice, s));
+    DevBuf<double> dR, dC, dP;
+    DevBuf<int> dS, dCnt;
+    SFM_TRY(dS.upload(samples, 6 * (size_t)n_hyp, s));
+    SFM_TRY(dR.alloc(9 * (size_t)n_hyp)); SFM_TRY(dC.alloc(3 * (size_t)n_hyp)); SFM_TRY(dP.alloc(24 * (size_t)n_hyp));
+    SFM_TRY(dCnt.alloc(2 * (size_t)n_hyp));
+    pnp_six_point_kernel<<<n_hyp, 64, 0, s>>>(n_hyp, n, dS.p, ses->dUV, ses->dX, ses->dK, dR.p, dC.p, dP.p, dP.p + 12 * (size_t)n_hyp);
+    pnp_score_kernel<<<2 * n_hyp, 256, 0, s>>>(n, dP.p, ses->dUV, ses->dX, threshold, dCnt.p);
+    SFM_HIP(hipGetLastError());
+    SFM_TRY(dR.download(R_out, 9 * (size_t)n_hyp, s)); SFM_TRY(dC.download(C_out, 3 * (size_t)n_hyp, s));
+    SFM_HIP(hipMemcpyAsync(counts, dCnt.p, sizeof(int) * n_hyp, hipMemcpyDeviceToHost, s));
+    SFM_HIP(hipMemcpyAsync(counts_neg, dCnt.p + n_hyp, sizeof(int) * n_hyp, hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    return SFM_OK;
+  };
+  const int st = run();
+  if (st != SFM_OK) return fail(st);
+  *out = ses;
+  return SFM_OK;
+}
+
+int sfm_pnp_ransac_finish(sfm_pnp_session* ses, const double R[9], const double C[3], double threshold, double lambda, int iters,
+                          int quirks, int* inlier_mask, int* n_inliers, double R_out[9], double C_out[3]) {
+  SFM_TRY(ensure_init());
+  if (ses == nullptr || ses->magic != kPnpSessionMagic) { set_error("sfm_pnp_ransac_finish: invalid session handle"); return SFM_E_HANDLE; }
+  if (iters < 0) { set_error("sfm_pnp_ransac_finish: iters < 0"); return SFM_E_SHAPE; }
+  const int n = ses->n;
+  // proj = K @ [R^T | R^T @ -C]  (campose:538) of the chosen pose; K comes from the caller's R, C only -- the session holds K
+  double Kh[9];
+  hipStream_t s = ctx().stream;
+  SFM_HIP(hipMemcpyAsync(Kh, ses->dK, sizeof(Kh), hipMemcpyDeviceToHost, s));
+  SFM_TRY(stream_sync(s));
+  double rt[12], P[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) rt[4 * i + j] = R[3 * j + i];
+    rt[4 * i + 3] = R[0 + i] * -C[0] + R[3 + i] * -C[1] + R[6 + i] * -C[2];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) P[4 * i + j] = Kh[3 * i] * rt[j] + Kh[3 * i + 1] * rt[4 + j] + Kh[3 * i + 2] * rt[8 + j];
+  auto run = [&]() -> int {
+    DevBuf<double> dP, dUVc, dXc, dR0, dC0, dR, dC;
+    DevBuf<int> dMask, dPos, dOff, dSt;
+    SFM_TRY(dP.upload(P, 12, s)); SFM_TRY(dR0.upload(R, 9, s)); SFM_TRY(dC0.upload(C, 3, s));
+    SFM_TRY(dMask.alloc(n)); SFM_TRY(dPos.alloc(n)); SFM_TRY(dOff.alloc(2)); SFM_TRY(dSt.alloc(1));
+    SFM_TRY(dUVc.alloc(3 * (size_t)n)); SFM_TRY(dXc.alloc(4 * (size_t)n)); SFM_TRY(dR.alloc(9)); SFM_TRY(dC.alloc(3));
+    pnp_inlier_mask_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dP.p, ses->dUV, ses->dX, threshold, dMask.p);
+    pnp_mask_scan_kernel<<<1, 1024, 0, s>>>(n, dMask.p, dPos.p, dOff.p);
+    pnp_compact_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, dMask.p, dPos.p, ses->dUV, ses->dX, dUVc.p, dXc.p);
+    SFM_HIP(hipGetLastError());
+    int off[2] = {0, 0};
+    SFM_TRY(dMask.download(inlier_mask, n, s));
+    SFM_HIP(hipMemcpyAsync(off, dOff.p, sizeof(off), hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    const int m = off[1];
+    if (n_inliers) *n_inliers = m;
+    // the refinement of the reference's call chain on exactly those columns (the size class follows m, as in sfm_pnp_nonlinear)
+    SFM_TRY(enqueue_pnp_nonlinear(1, dOff.p, n, dUVc.p, dXc.p, ses->dK, dR0.p, dC0.p, lambda, iters, quirks, dR.p, dC.p, dSt.p, s, m, std::max(m, 1)));
+    int st = SFM_OK;
+    SFM_TRY(dR.download(R_out, 9, s)); SFM_TRY(dC.download(C_out, 3, s));
+    SFM_HIP(hipMemcpyAsync(&st, dSt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    SFM_TRY(stream_sync(s));
+    if (st != SFM_OK) set_error("sfm_pnp_ransac_finish: rotation check failed on device (status %d)", st);
+    return st;
+  };
+  const int st = run();
+  const int sd = sfm_pnp_session_destroy(ses);
+  return st != SFM_OK ? st : sd;
 }
 
 int sfm_pnp_nonlinear_batch(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,

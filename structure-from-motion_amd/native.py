@@ -29,6 +29,7 @@ EXPORTS = (
     "sfm_quat_to_rot", "sfm_rot_to_quat", "sfm_jac_cam", "sfm_jac_pt",
     "sfm_tri_nonlinear", "sfm_tri_linear", "sfm_triangulate", "sfm_pnp_nonlinear", "sfm_pnp_nonlinear_batch",
     "sfm_pnp_linear_ransac", "sfm_pnp_six_point_hypotheses", "sfm_pnp_ransac_evaluate", "sfm_pnp_inlier_mask",
+    "sfm_pnp_ransac_begin", "sfm_pnp_ransac_finish", "sfm_pnp_session_destroy",
     "sfm_comm_available", "sfm_comm_unique_id", "sfm_comm_create", "sfm_comm_destroy", "sfm_ba_set_comm",
     "sfm_fundamental_ransac", "sfm_fundamental_eight_point", "sfm_essential_from_fundamental", "sfm_pose_candidates",
     "sfm_cheirality",
@@ -365,6 +366,46 @@ def pnp_ransac_evaluate(uv_pix, pts_h, intrinsic, samples, threshold):
     check(lib.sfm_pnp_ransac_evaluate(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples),
                                       float(threshold), dptr(rot), dptr(loc), iptr(cnt), iptr(cnt_neg)))
     return rot, loc, cnt, cnt_neg
+
+
+def pnp_ransac_begin(uv_pix, pts_h, intrinsic, samples, threshold):
+    """``pnp_ransac_evaluate`` that keeps the view's keys and points on the device: returns (session handle, rot (n_hyp,3,3),
+    loc (n_hyp,3), counts, counts_neg).  The handle goes to ``pnp_ransac_finish`` (or ``pnp_session_destroy``)."""
+    uv_pix = f64(uv_pix); pts_h = f64(pts_h); intrinsic = f64(intrinsic)
+    samples = i32(samples).reshape(-1, 6)
+    n, n_hyp = uv_pix.shape[1], samples.shape[0]
+    rot = np.empty((n_hyp, 3, 3)); loc = np.empty((n_hyp, 3))
+    cnt = np.empty(n_hyp, dtype=np.int32); cnt_neg = np.empty(n_hyp, dtype=np.int32)
+    handle = ctypes.c_void_p()
+    lib = load()
+    lib.sfm_pnp_ransac_begin.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_double, _dp, _dp, _ip, _ip,
+                                         ctypes.POINTER(ctypes.c_void_p)]
+    check(lib.sfm_pnp_ransac_begin(n, dptr(uv_pix), dptr(pts_h), dptr(intrinsic), n_hyp, iptr(samples), float(threshold),
+                                   dptr(rot), dptr(loc), iptr(cnt), iptr(cnt_neg), ctypes.byref(handle)))
+    return (handle, n), rot, loc, cnt, cnt_neg
+
+
+def pnp_ransac_finish(session, rot, loc, threshold, lam, iters, quirks=QUIRKS_REFERENCE):
+    """Inlier mask of the pose (rot, loc) on the session's resident view, the inlier columns compacted on the device, ``iters``
+    nonlinear PnP iterations on them: returns (inlier indices (int array, ascending), R (3,3), C (3,1)).  Releases the session."""
+    handle, n = session
+    rot = f64(rot); loc = f64(loc).reshape(3)
+    mask = np.empty(n, dtype=np.int32)
+    cnt = ctypes.c_int()
+    r_out = np.empty((3, 3)); c_out = np.empty(3)
+    lib = load()
+    lib.sfm_pnp_ransac_finish.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                          _ip, _ip, _dp, _dp]
+    check(lib.sfm_pnp_ransac_finish(handle, dptr(rot), dptr(loc), float(threshold), float(lam), int(iters), int(quirks),
+                                    iptr(mask), ctypes.byref(cnt), dptr(r_out), dptr(c_out)))
+    return np.flatnonzero(mask), r_out, c_out.reshape(3, 1)
+
+
+def pnp_session_destroy(session):
+    handle, _n = session
+    lib = load()
+    lib.sfm_pnp_session_destroy.argtypes = [ctypes.c_void_p]
+    check(lib.sfm_pnp_session_destroy(handle))
 
 
 def pnp_inlier_mask(uv_pix, pts_h, intrinsic, rot, loc, threshold, as_array=False):

@@ -161,11 +161,7 @@ class HipCamposeMixin:
         inliers, rot, loc = self._linear_pnp(key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
         return inliers.tolist(), rot, loc
 
-    def _linear_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config):
-        """``linear_estimate_cam_pose_pnp`` with the inlier indices as an int array (the list the reference returns costs
-        0.1 ms to build and 0.25 ms to turn back into an index at 5 000 inliers: ``estimate_cam_pose_pnp`` builds it once)."""
-        if not ransac_config:
-            ransac_config = self.ransac_config
+    def _check_pnp_input(self, key_2d_pts, tri_3d_pts):
         if key_2d_pts.shape[1] != tri_3d_pts.shape[1]:
             logging.warning('%s : different numbers of key points and of triangulated points',
                             self.__class__.__name__)
@@ -175,15 +171,12 @@ class HipCamposeMixin:
         if num_pts < 6:
             logging.warning('%s : required equal or more than six points %d', self.__class__.__name__, num_pts)
             raise ValueError("required equal or more than six points {}".format(num_pts))
-        samples = sample_indices(num_pts, 6, ransac_config.iteration, as_array=True)       # = [random.sample(range(num_pts), 6) ...], campose:531
-        if not self.reproduce_q13:
-            rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
-                key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold, as_array=True)
-            return inlier_indices, rot, loc
-        # Quirk Q13 (q13.py): the device solves and scores every hypothesis, under its centre C and under -C; which of the
-        # two the reference would have scored is its LAPACK's decision, asked of NumPy for the hypotheses that can still win
-        rots, locs, counts, counts_neg = native.pnp_ransac_evaluate(
-            key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+        return num_pts
+
+    def _q13_winner(self, key_2d_pts, tri_3d_pts, intrinsic_mat, samples, rots, locs, counts, counts_neg):
+        """Quirk Q13 (q13.py): the device has solved and scored every hypothesis, under its centre C and under -C; which of
+        the two the reference would have scored is its LAPACK's decision, asked of NumPy for the hypotheses that can still
+        win.  Returns (rot, loc) of the reference's winner, or None when no hypothesis has an inlier."""
         kinv = np.linalg.inv(intrinsic_mat)
 
         def fires(h):
@@ -193,10 +186,27 @@ class HipCamposeMixin:
         best, fired = reference_winner(counts, counts_neg, fires)
         self.ransac_last = {"hypothesis": best, "q13_fired": fired,
                             "sane_winner": int(np.argmax(counts)) if counts.max() > 0 else -1}
-        if best < 0:                                   # no hypothesis has an inlier: the initial pose (campose:519-522)
+        if best < 0:
+            return None
+        return rots[best].copy(), (-locs[best] if fired else locs[best]).reshape(3, 1).copy()
+
+    def _linear_pnp(self, key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config):
+        """``linear_estimate_cam_pose_pnp`` with the inlier indices as an int array (the list the reference returns costs
+        0.1 ms to build and 0.25 ms to turn back into an index at 5 000 inliers: ``estimate_cam_pose_pnp`` builds it once)."""
+        if not ransac_config:
+            ransac_config = self.ransac_config
+        num_pts = self._check_pnp_input(key_2d_pts, tri_3d_pts)
+        samples = sample_indices(num_pts, 6, ransac_config.iteration, as_array=True)       # = [random.sample(range(num_pts), 6) ...], campose:531
+        if not self.reproduce_q13:
+            rot, loc, inlier_indices, _best = native.pnp_linear_ransac(
+                key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold, as_array=True)
+            return inlier_indices, rot, loc
+        rots, locs, counts, counts_neg = native.pnp_ransac_evaluate(
+            key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+        won = self._q13_winner(key_2d_pts, tri_3d_pts, intrinsic_mat, samples, rots, locs, counts, counts_neg)
+        if won is None:                                # no hypothesis has an inlier: the initial pose (campose:519-522)
             return np.empty(0, dtype=np.intp), np.identity(3), np.zeros((3, 1))
-        rot = rots[best].copy()
-        loc = (-locs[best] if fired else locs[best]).reshape(3, 1).copy()
+        rot, loc = won
         inlier_indices = native.pnp_inlier_mask(key_2d_pts, tri_3d_pts, intrinsic_mat, rot, loc, ransac_config.inlier_threshold,
                                                 as_array=True)
         return inlier_indices, rot, loc
@@ -209,7 +219,26 @@ class HipCamposeMixin:
             damping_factor = self.damping_factor
         if not iteration:
             iteration = self.iteration
-        sel, ini_rot, ini_loc = self._linear_pnp(key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
+        if self.reproduce_q13:
+            # RANSAC evaluation and refinement around the host's choice of the winner, the view resident on the device in
+            # between (sfm_pnp_ransac_begin / _finish): one upload of the keys and points, no host-side gather of the inliers
+            num_pts = self._check_pnp_input(key_2d_pts, tri_3d_pts)
+            samples = sample_indices(num_pts, 6, ransac_config.iteration, as_array=True)   # campose:531
+            session, rots, locs, counts, counts_neg = native.pnp_ransac_begin(
+                key_2d_pts, tri_3d_pts, intrinsic_mat, samples, ransac_config.inlier_threshold)
+            try:
+                won = self._q13_winner(key_2d_pts, tri_3d_pts, intrinsic_mat, samples, rots, locs, counts, counts_neg)
+            except BaseException:
+                native.pnp_session_destroy(session)
+                raise
+            if won is not None:
+                sel, ref_rot, ref_loc = native.pnp_ransac_finish(session, won[0], won[1], ransac_config.inlier_threshold,
+                                                                 damping_factor, iteration, self.quirk_flags)
+                return sel.tolist(), ref_rot, ref_loc      # a list is the reference's return type (campose:246)
+            native.pnp_session_destroy(session)
+            sel, ini_rot, ini_loc = np.empty(0, dtype=np.intp), np.identity(3), np.zeros((3, 1))      # campose:519-522
+        else:
+            sel, ini_rot, ini_loc = self._linear_pnp(key_2d_pts, tri_3d_pts, intrinsic_mat, ransac_config)
         ref_rot, ref_loc = self.nonlinear_estimate_cam_pose_pnp(
             key_2d_pts[:, sel], tri_3d_pts[:, sel], intrinsic_mat,
             ini_rot, ini_loc, damping_factor, iteration)

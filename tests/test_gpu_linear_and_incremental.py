@@ -142,6 +142,44 @@ def test_pnp_linear_ransac_synthetic_with_outliers(hip, sfm):
     assert rel(r, rot) < 1e-6 and rel(c, loc) < 1e-5
 
 
+@pytest.mark.parametrize("n", [40, 900, 3500, 5000])
+def test_pnp_ransac_session_equals_the_separate_calls(hip, sfm, n):
+    """sfm_pnp_ransac_begin / _finish (the view resident between the RANSAC evaluation and the refinement; inlier columns
+    compacted on the device) = sfm_pnp_ransac_evaluate, then sfm_pnp_inlier_mask, then sfm_pnp_nonlinear on the columns the
+    host gathered (campose_processor.py:231-243) -- bit for bit: the chosen pose, the pose with the centre negated (quirk
+    Q13's branch), a pose nothing fits, and a session that is dropped unfinished."""
+    rng = np.random.default_rng(40 + n)
+    sc = sfm.scenes.make_scene(2, n, 1.0, seed=70 + n, pixel_noise=0.4)
+    K = sc.intrinsic
+    uv = np.vstack((sc.uv_pix[:, sc.cam_idx == 1], np.ones((1, n))))
+    bad = rng.choice(n, n // 5, replace=False)
+    uv[0:2, bad] += rng.uniform(20, 150, (2, bad.size)) * rng.choice([-1, 1], (2, bad.size))
+    x = np.vstack((sc.pts_true, np.ones((1, n))))
+    samples = np.array([rng.choice(n, 6, replace=False) for _ in range(120)], dtype=np.int32)
+    rots, locs, cnt, cneg = hip.pnp_ransac_evaluate(uv, x, K, samples, 8.0)
+    best = int(np.argmax(cnt))
+    assert cnt[best] >= n - bad.size - 2
+    for rot, loc in ((rots[best], locs[best]), (rots[best], -locs[best]), (np.eye(3), np.array([0.0, 0.0, 1e6]))):
+        ses, r2, l2, c2, cn2 = hip.pnp_ransac_begin(uv, x, K, samples, 8.0)
+        assert np.array_equal(r2, rots) and np.array_equal(l2, locs) and np.array_equal(c2, cnt) and np.array_equal(cn2, cneg)
+        idx = hip.pnp_inlier_mask(uv, x, K, rot, loc, 8.0, as_array=True)
+        try:
+            r_sep, c_sep = hip.pnp_nonlinear(uv[:, idx], x[:, idx], K, rot, loc, 5.0, 25)
+            sep_error = None
+        except ValueError as err:                      # the refinement of a hopeless pose may leave the rotation group
+            sep_error = str(err)
+        if sep_error is None:
+            idx2, r_ses, c_ses = hip.pnp_ransac_finish(ses, rot, loc, 8.0, 5.0, 25)
+            assert np.array_equal(idx2, idx) and np.array_equal(r_ses, r_sep) and np.array_equal(c_ses, c_sep)
+        else:
+            with pytest.raises(ValueError):
+                hip.pnp_ransac_finish(ses, rot, loc, 8.0, 5.0, 25)
+    ses, *_ = hip.pnp_ransac_begin(uv, x, K, samples, 8.0)
+    hip.pnp_session_destroy(ses)                       # never finished: released explicitly
+    with pytest.raises(ValueError):
+        hip.pnp_ransac_begin(uv[:, :5], x[:, :5], K, samples[:, :] % 5, 8.0)      # fewer than six points
+
+
 def test_incremental_sfm_loop(hip, sfm, oracle):
     """Synthetic stand-in for BASELINE config 5 (the upenn BMPs need SIFT): views arrive one by one;
     each new view is posed by nonlinear PnP on the points known so far, new points are triangulated
