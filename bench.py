@@ -808,7 +808,8 @@ class Stopwatch:
 
     def install(self):
         n = self.native
-        for name in ("pnp_linear_ransac", "pnp_nonlinear", "triangulate", "tri_nonlinear", "tri_linear", "ba_solve"):
+        for name in ("pnp_linear_ransac", "pnp_ransac_evaluate", "pnp_inlier_mask", "pnp_ransac_begin", "pnp_ransac_finish", "pnp_nonlinear",
+                     "triangulate", "tri_nonlinear", "tri_linear", "ba_solve"):
             self.wrap(n, name)
         for name in ("__init__", "iterate", "get_state", "get_state_rot", "rederive_quaternions", "append", "set_cameras", "set_points", "set_state"):
             self.wrap(n.BaProblem, name)
@@ -878,6 +879,7 @@ def run_c5(args, ctx):
                 inl, r_new, c_new = cp.estimate_cam_pose_pnp(uv[c][:, idx], full[:, idx], K)          # ba_processor.py:191
                 stage["pnp_s"] = time.perf_counter() - t0
                 stage["pnp_native_s"] = sw.take()
+                stage["pnp_native_calls_ms"] = {k: round(v * 1e3, 4) for k, v in sw.last_by_name.items()}
                 stage["pnp_inliers"] = len(inl)
             else:
                 r_new = rots[c] @ Rotation.from_rotvec(rng.normal(0, 0.002, 3)).as_matrix()     # second view: pose from the two-view initialisation
@@ -933,6 +935,8 @@ def run_c5(args, ctx):
         agg = {k: float(np.median([r[k] for r in rows])) for k in rows[0] if k.endswith("_s")}
         agg.update({k: rows[0][k] for k in ("views", "points", "observations", "ba_action", "ba_upload_bytes")})
         agg["ba_native_calls_ms"] = {k: float(np.median([r["ba_native_calls_ms"].get(k, 0.0) for r in rows])) for k in rows[0]["ba_native_calls_ms"]}
+        if "pnp_native_calls_ms" in rows[0]:
+            agg["pnp_native_calls_ms"] = {k: float(np.median([r["pnp_native_calls_ms"].get(k, 0.0) for r in rows])) for k in rows[0]["pnp_native_calls_ms"]}
         agg["host_python_s"] = agg["view_s"] - sum(agg.get(k, 0.0) for k in ("pnp_native_s", "triangulate_native_s", "ba_native_s"))
         per_view.append(agg)
     out = {

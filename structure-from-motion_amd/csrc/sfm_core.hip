@@ -1552,6 +1552,7 @@ struct sfm_pnp_session {
   unsigned magic;
   int n;
   double *dUV, *dX, *dK;
+  double K[9];       // host copy (the projection of the chosen pose is formed on the host side of the library)
 };
 namespace sfm { constexpr unsigned kPnpSessionMagic = 0x5F3B5E55u; }
 
@@ -1574,7 +1575,8 @@ int sfm_pnp_ransac_begin(int n, const double* uv_pix, const double* X, const dou
   for (int i = 0; i < 6 * n_hyp; ++i)
     if (samples[i] < 0 || samples[i] >= n) { set_error("sfm_pnp_ransac_begin: sample index %d out of range", samples[i]); return SFM_E_SHAPE; }
   hipStream_t s = ctx().stream;
-  sfm_pnp_session* ses = new sfm_pnp_session{kPnpSessionMagic, n, nullptr, nullptr, nullptr};
+  sfm_pnp_session* ses = new sfm_pnp_session{kPnpSessionMagic, n, nullptr, nullptr, nullptr, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+  for (int i = 0; i < 9; ++i) ses->K[i] = K[i];
   auto fail = [&](int st) { (void)sfm_pnp_session_destroy(ses); return st; };
   if (pool_alloc(reinterpret_cast<void**>(&ses->dUV), sizeof(double) * 3 * (size_t)n) != hipSuccess ||
       pool_alloc(reinterpret_cast<void**>(&ses->dX), sizeof(double) * 4 * (size_t)n) != hipSuccess ||
@@ -1612,11 +1614,9 @@ int sfm_pnp_ransac_finish(sfm_pnp_session* ses, const double R[9], const double 
   if (ses == nullptr || ses->magic != kPnpSessionMagic) { set_error("sfm_pnp_ransac_finish: invalid session handle"); return SFM_E_HANDLE; }
   if (iters < 0) { set_error("sfm_pnp_ransac_finish: iters < 0"); return SFM_E_SHAPE; }
   const int n = ses->n;
-  // proj = K @ [R^T | R^T @ -C]  (campose:538) of the chosen pose; K comes from the caller's R, C only -- the session holds K
-  double Kh[9];
+  // proj = K @ [R^T | R^T @ -C]  (campose:538) of the chosen pose
+  const double* Kh = ses->K;
   hipStream_t s = ctx().stream;
-  SFM_HIP(hipMemcpyAsync(Kh, ses->dK, sizeof(Kh), hipMemcpyDeviceToHost, s));
-  SFM_TRY(stream_sync(s));
   double rt[12], P[12];
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) rt[4 * i + j] = R[3 * j + i];
