@@ -607,8 +607,8 @@ struct PnpSplitWs {
   double* xch;   // [n_views][2][kmax][35]
   int* ctr;      // [n_views] arrivals (monotone over the iterations of one launch; cleared before it)
   int kmax;
+  int slice_pts; // points per slice (<= 1024: four register-resident points per thread)
 };
-constexpr int kPnpSplitSlice = 1024;
 
 template <int THREADS, int PNP_CACHE, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __restrict__ offsets, int total,
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
                                                                 int quirks, double* __restrict__ R_out,
                                                                 double* __restrict__ C_out, int* __restrict__ status,
                                                                 int stage_mode, int stage_cap, int n_lo, int n_hi,
-                                                                PnpSplitWs ws = PnpSplitWs{nullptr, nullptr, 1}, int view0 = 0) {
+                                                                PnpSplitWs ws = PnpSplitWs{nullptr, nullptr, 1, 1024}, int view0 = 0) {
   // Views too large for the register cache keep their points in LDS when they fit (stage_mode 1: X, Y, Z, W and the
   // normalised key, 48 bytes per point, SoA over stage_cap points; 2: the normalised key only, the point is re-read from
   // L2): the key normalisation -- two divisions per point -- is then done once, not in every iteration.
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
   const int base = offsets[view];
   const int n = offsets[view + 1] - base;
   if (n < n_lo || n > n_hi) return;          // the other size class' launch refines this view (enqueue_pnp_nonlinear)
-  const int nslices = SPLIT ? (n + kPnpSplitSlice - 1) / kPnpSplitSlice : 1;
+  const int nslices = SPLIT ? (n + ws.slice_pts - 1) / ws.slice_pts : 1;
   if (SPLIT && slice >= nslices) return;
   const int per = SPLIT ? (n + nslices - 1) / nslices : n;
   const int p_lo = slice * per;                          // this workgroup's points: [p_lo, p_lo + n_mine) of the view
@@ -1073,6 +1073,10 @@ static int pnp_split_min() {
   return v;
 }
 
+// points per slice of a split view: 1 024 = four register-resident points per thread.  Smaller slices lose: every sibling adds
+// ~0.25 us to the hand-over (5 000 points: 5.65 us per iteration at 1 024, 6.61 at 512, 9.60 at 256; profiles/r4/time_pnp_slices.txt)
+static int pnp_split_slice() { return 1024; }
+
 static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, const double* uv_pix, const double* X,
                                  const double* K, const double* R0, const double* C0, double lambda, int iters, int quirks,
                                  double* R_out, double* C_out, int* status, hipStream_t s, int narrowest, int widest) {
@@ -1116,9 +1120,11 @@ static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, con
                                                           kSmall + 1, split_min - 1);
   }
   if (split_class) {
-    const int kmax = (widest + kPnpSplitSlice - 1) / kPnpSplitSlice;
+    const int slice_pts = pnp_split_slice();
+    const int kmax = (widest + slice_pts - 1) / slice_pts;
     PnpSplitWs ws;
     SFM_TRY(pnp_split_workspace(s, n_views, kmax, &ws));
+    ws.slice_pts = slice_pts;
     SFM_HIP(hipMemsetAsync(ws.ctr, 0, sizeof(int) * (size_t)n_views, s));
     // the slices of a view wait for each other inside the launch: keep a launch's workgroups within what is resident at
     // once (sibling workgroups are neighbours in the grid; workgroups of views of other classes leave at once)
