@@ -598,14 +598,15 @@ __device__ __forceinline__ void solve7_spd(double (&a)[28], double (&b)[7]) {
 // 1000 points 256 threads x 4 points take 4.6 us per iteration against 5.5 us for 512 x 2 (profiles/r3/bench_pnp_*.json).
 // SPLIT (round 4, third size class): a view of more than kPnpSplitMin points is dealt to k = ceil(n / 1024) workgroups of the
 // 256-thread, register-resident form (workgroup = blockIdx.x % kmax of view blockIdx.x / kmax; slices of ceil(n / k) points).
-// Per iteration every workgroup stores the 35 sums of its slice, arrives at the view's device-scope counter, waits until
-// all k have arrived and adds the k partial vectors IN SLICE ORDER -- so every workgroup holds the same bits, carries out
-// the same serial part and no camera has to be published (one hand-over per iteration, ~2 us, instead of two).  The
-// partial vectors are double-buffered by iteration parity: a workgroup cannot be two arrivals ahead of a sibling.
+// Per iteration every workgroup stores the 35 sums of its slice, publishes its flag word (iterations published), waits until
+// every sibling's flag says the same and adds the k partial vectors IN SLICE ORDER -- so every workgroup holds the same bits,
+// carries out the same serial part and no camera has to be published (one hand-over per iteration, ~2 us, instead of two).
+// The partial vectors are double-buffered by iteration parity: a workgroup cannot be two iterations ahead of a sibling (it
+// needs the sibling's flag of the iteration in between, which the sibling sets after it has read the older vectors).
 // Which kernel refines a view still depends on the view's own size only.
 struct PnpSplitWs {
   double* xch;   // [n_views][2][kmax][35]
-  int* ctr;      // [n_views] arrivals (monotone over the iterations of one launch; cleared before it)
+  int* ctr;      // [n_views][kmax] per-slice flag words: iterations published (monotone over a launch; cleared before it)
   int kmax;
   int slice_pts; // points per slice (<= 1024: four register-resident points per thread)
 };
@@ -784,24 +785,29 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
       else sums[tid] = t;
     }
     if (SPLIT) {
-      // hand-over: wave 0 stored the slice's sums -> agent-scope release -> arrive -> wait for all slices of the view ->
-      // barrier -> agent-scope acquire -> the partial vectors of all slices, added in slice order
+      // hand-over (the general recipe of the CDNA guide): wave 0 stored the slice's sums -> agent-scope release -> its flag
+      // word = iterations published -> lane g polls sibling g's flag (no read-modify-write on a shared counter) -> workgroup
+      // barrier -> agent-scope acquire -> the partial vectors of all slices, added in slice order.
+      // (Measured and not kept: the sums as sc1 stores / loads in place of the two fences, 5.44 instead of 5.66 us per iteration at
+      //  5 000 points -- the guide lists that form as measured for one workgroup per CU only.)
       if (wave == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (tid == 0) {
-          __hip_atomic_fetch_add(ws.ctr + view, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          const int want = nslices * (it + 1);
-          const unsigned long long t0 = wall_clock64();
-          while (__hip_atomic_load(ws.ctr + view, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (wall_clock64() - t0 > 200000000ull) { split_fail = 1; break; }      // 2 s: a sibling never ran (never seen)
-            __builtin_amdgcn_s_sleep(1);
-          }
+        int* flags = ws.ctr + (size_t)view * ws.kmax;
+        if (tid == 0) __hip_atomic_store(flags + slice, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int want = it + 1;
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+          bool mine = true;
+          for (int g = lane; g < nslices; g += 64)
+            mine = mine && __hip_atomic_load(flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+          if (__all(mine)) break;
+          if (wall_clock64() - t0 > 200000000ull) { if (lane == 0) split_fail = 1; break; }      // 2 s: a sibling never ran (never seen)
+          __builtin_amdgcn_s_sleep(1);
         }
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (split_fail) { st = SFM_E_HIP; break; }
-      if (tid < 35) {
+      if (tid < 35 && !split_fail) {
         const double* part = ws.xch + (((size_t)view * 2 + (it & 1)) * ws.kmax) * 35 + tid;
         double t = part[0];
         for (int g = 1; g < nslices; ++g) t += part[(size_t)g * 35];
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(THREADS) void pnp_nonlinear_kernel(const int* __res
       }
     }
     __syncthreads();
+    if (SPLIT && split_fail) { st = SFM_E_HIP; break; }
     double a[28], b[7];
 #pragma unroll
     for (int k = 0; k < 28; ++k) a[k] = sums[k];
@@ -1054,10 +1061,10 @@ static int pnp_split_workspace(hipStream_t s, int n_views, int kmax, PnpSplitWs*
     SFM_HIP(pool_alloc(reinterpret_cast<void**>(&e->xch), sizeof(double) * need));
     e->xch_doubles = need;
   }
-  if (n_views > e->views) {
+  if (n_views * kmax > e->views) {          // (views = flag words held)
     if (e->ctr) { SFM_HIP(hipStreamSynchronize(s)); pool_free(e->ctr); e->ctr = nullptr; }
-    SFM_HIP(pool_alloc(reinterpret_cast<void**>(&e->ctr), sizeof(int) * (size_t)n_views));
-    e->views = n_views;
+    SFM_HIP(pool_alloc(reinterpret_cast<void**>(&e->ctr), sizeof(int) * (size_t)n_views * kmax));
+    e->views = n_views * kmax;
   }
   out->xch = e->xch; out->ctr = e->ctr; out->kmax = kmax;
   return SFM_OK;
@@ -1125,7 +1132,7 @@ static int enqueue_pnp_nonlinear(int n_views, const int* offsets, int total, con
     PnpSplitWs ws;
     SFM_TRY(pnp_split_workspace(s, n_views, kmax, &ws));
     ws.slice_pts = slice_pts;
-    SFM_HIP(hipMemsetAsync(ws.ctr, 0, sizeof(int) * (size_t)n_views, s));
+    SFM_HIP(hipMemsetAsync(ws.ctr, 0, sizeof(int) * (size_t)n_views * kmax, s));
     // the slices of a view wait for each other inside the launch: keep a launch's workgroups within what is resident at
     // once (sibling workgroups are neighbours in the grid; workgroups of views of other classes leave at once)
     const int views_per_launch = std::max(1, 2 * ctx().num_cus / kmax);
