@@ -614,10 +614,14 @@ int ba_schur_plan(sfm_ba_problem* p) {
   // per-point block offsets blk_ptr[p][b] = first observation of point p whose camera is >= 18 b (b = nblk: the
   // end of the track); filled on the device by ba_structure_kernel
   SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->schur_blk_ptr), sizeof(int) * (size_t)std::max(1, d.N) * (pp.nblk + 1)));
-  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
-  SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes));
+  // once per device (every sfm_ba_create / sfm_ba_append plans a problem: the per-view loop of the reference appends after every
+  // registered view); a process that re-initialises the library on another device sets them again
+  static int attr_device = -1;
+  if (attr_device != ctx().device) {
+    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSchurLdsBytes));
+    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPairLdsBytes));
+    attr_device = ctx().device;
+  }
   return SFM_OK;
 }
 
