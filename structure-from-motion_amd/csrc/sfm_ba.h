@@ -161,6 +161,7 @@ struct sfm_ba_problem {
   int* rows_first = nullptr;               // [groups+1] first workgroup of every camera group
   void* rows_ws = nullptr;                 // [rows_wgs][7 R][tpr] split-K panels
   int rows_R = 0, rows_tpr = 0, rows_wgs = 0, rows_groups = 0;
+  int rows_tpl = 0, rows_cp = 7;          // LDS row pitch and camera pitch of the panel (experiment: 8)
   // SFM_OPT_GRAPH: the steady-state iteration body (fused linearise + Schur + reduce + solve) captured once per
   // camera-slot parity and replayed by sfm_ba_iterate; dropped whenever an option, the stream, the reduced buffer or
   // the structure changes

@@ -591,7 +591,7 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   std::swap(p->cam_ptr, q->cam_ptr); std::swap(p->cam_ent, q->cam_ent); std::swap(p->cam_pairs, q->cam_pairs);
   std::swap(p->rows_table, q->rows_table); std::swap(p->rows_first, q->rows_first); std::swap(p->rows_ws, q->rows_ws);
   std::swap(p->rows_R, q->rows_R); std::swap(p->rows_tpr, q->rows_tpr); std::swap(p->rows_wgs, q->rows_wgs);
-  std::swap(p->rows_groups, q->rows_groups);
+  std::swap(p->rows_groups, q->rows_groups); std::swap(p->rows_tpl, q->rows_tpl); std::swap(p->rows_cp, q->rows_cp);
   std::swap(p->max_track, q->max_track);
   // deterministic mode holds for the grown scene only while the dense product fits and the camera accumulators stay in
   // LDS (V <= 234): beyond that the handle falls back to the default path instead of mixing the two reduce kernels

@@ -75,15 +75,15 @@ struct RowsWg { int group, e_beg, e_end, pad; };
 
 __global__ __launch_bounds__(ROWS_THREADS) void ba_schur_rows_kernel(BaDev d, const int4* __restrict__ cam_ent,
                                                                     const RowsWg* __restrict__ table, double* __restrict__ ws,
-                                                                    int R, int tpr) {
-  extern __shared__ double panel[];          // [7 R][tpr]
+                                                                    int R, int tpr, int tpl, int cp) {
+  extern __shared__ double panel[];          // [7 R][tpl]: camera c' at column cp * c' (cp = 7, or 8: fewer LDS bank conflicts)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const RowsWg wg = table[blockIdx.x];
   const int gbase = wg.group * R;
   const int nrows = 7 * min(R, d.V - gbase);
   const int ncols = 7 * min(d.V, gbase + R);           // columns beyond the group's last camera are never touched
-  for (int t = tid; t < nrows * tpr; t += ROWS_THREADS) panel[t] = 0.0;
+  for (int t = tid; t < nrows * tpl; t += ROWS_THREADS) panel[t] = 0.0;
   __syncthreads();
   const double* __restrict__ Z = d.Z;
   typedef const __attribute__((address_space(4))) double ConstF64;
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(ROWS_THREADS) void ba_schur_rows_kernel(BaDev d, co
     v.oa = __builtin_amdgcn_readfirstlane(en.x);
     v.b0 = __builtin_amdgcn_readfirstlane(en.y);
     v.kB = __builtin_amdgcn_readfirstlane(en.w);
-    v.rowoff = 7 * (__builtin_amdgcn_readfirstlane(en.z) - gbase) * tpr;
+    v.rowoff = 7 * (__builtin_amdgcn_readfirstlane(en.z) - gbase) * tpl;
   };
   auto load_round = [&](const Visit& v, int bb, double& z0, double& z1, double& z2, int& col) {
     const bool on = slot_ok && bb + lb < v.kB;
     const int ob = v.b0 + bb + (on ? lb : 0);
     const double* q = Z + (size_t)ob * 21 + 3 * lj;
     z0 = q[0]; z1 = q[1]; z2 = q[2];
-    col = on ? 7 * d.cam_idx[ob] + lj : -1;
+    col = on ? cp * d.cam_idx[ob] + lj : -1;
   };
   Visit cur, nxt;
   int e = wg.e_beg + wave;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(ROWS_THREADS) void ba_schur_rows_kernel(BaDev d, co
       if (col >= 0) {
         double* pc = prow + col;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) atomicAdd(pc + i * tpr, za[3 * i] * z0 + za[3 * i + 1] * z1 + za[3 * i + 2] * z2);
+        for (int i = 0; i < 7; ++i) atomicAdd(pc + i * tpl, za[3 * i] * z0 + za[3 * i + 1] * z1 + za[3 * i + 2] * z2);
       }
       z0 = n0; z1 = n1; z2 = n2; col = ncol;
     }
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(ROWS_THREADS) void ba_schur_rows_kernel(BaDev d, co
   double* slab = ws + (size_t)blockIdx.x * ((size_t)7 * R * tpr);
   for (int t = tid; t < nrows * ncols; t += ROWS_THREADS) {
     const int r = t / ncols, c = t - r * ncols;
-    slab[(size_t)r * tpr + c] = panel[r * tpr + c];
+    const int cam = c / 7;
+    slab[(size_t)r * tpr + c] = panel[r * tpl + cp * cam + (c - 7 * cam)];
   }
 }
 
@@ -191,7 +192,18 @@ int ba_rows_plan(sfm_ba_problem* p) {
   p->rows_ok = false;
   if (d.M == 0 || d.N == 0) return SFM_OK;
   const int tpr = ((7 * d.V + 1) / 2) * 2;
-  const int R = (int)std::min<size_t>((size_t)d.V, kRowsLdsBudget / ((size_t)7 * tpr * sizeof(double)));
+  // Camera pitch of the LDS panel.  A lane round adds 9 x 7 columns of one panel row; with the natural pitch of 7 the nine
+  // 7-wide groups of a sparse track sit at random offsets of the 32 bank pairs (worst bank pair 4.1 lanes on average at 15 %
+  // visibility, ideal 2), with a pitch of 8 they fall into four classes (3.7).  Measured (profiles/r4/ab_rows_pitch.txt,
+  // profiles/r4/time_schur_rows_pitch.txt; us per launch, pitch 7 / 8): 200 cameras @ 0.15 (the C4 share) 325 / 285;
+  // 100 @ 0.25: 202 / 191; 120 @ 0.1: 62 / 62; 60 @ 0.3: 97 / 99; 80 @ 0.4: 281 / 290; 50 @ 0.6 (C3 through this kernel)
+  // 428 / 452 -- dense tracks are the other way round (consecutive cameras tile the banks exactly with pitch 7) -- so the
+  // pitch follows the scene's visibility.  SFM_ROWS_PITCH8 = 0 / 1 forces it (A/B runs).
+  static const int forced = [] { const char* e = getenv("SFM_ROWS_PITCH8"); return e ? (atoi(e) == 1 ? 8 : 7) : 0; }();
+  const double visibility = (double)d.M / ((double)d.N * (double)d.V);
+  const int cp = forced ? forced : (visibility <= 0.25 ? 8 : 7);
+  const int tpl = cp == 7 ? tpr : 8 * d.V;
+  const int R = (int)std::min<size_t>((size_t)d.V, kRowsLdsBudget / ((size_t)7 * tpl * sizeof(double)));
   if (R < 1) return SFM_OK;                 // more than ~2800 cameras: the 18-camera tile kernel takes over
   const int G = (d.V + R - 1) / R;
   double total = 0;
@@ -226,6 +238,7 @@ int ba_rows_plan(sfm_ba_problem* p) {
   SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kRowsLdsBudget));
   p->rows_R = R; p->rows_tpr = tpr; p->rows_wgs = (int)table.size(); p->rows_groups = G;
+  p->rows_tpl = tpl; p->rows_cp = cp;
   p->rows_ok = true;
   return SFM_OK;
 }
@@ -234,10 +247,10 @@ int ba_rows_plan(sfm_ba_problem* p) {
 // ba_schur_reduce with no tiles).
 int ba_rows_enqueue(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
-  const size_t lds = sizeof(double) * (size_t)7 * p->rows_R * p->rows_tpr;
+  const size_t lds = sizeof(double) * (size_t)7 * p->rows_R * p->rows_tpl;
   ba_tick(p, SFM_K_SCHUR, true, s);
   ba_schur_rows_kernel<<<p->rows_wgs, ROWS_THREADS, lds, s>>>(d, static_cast<const int4*>(p->cam_ent), static_cast<const RowsWg*>(p->rows_table),
-                                                             static_cast<double*>(p->rows_ws), p->rows_R, p->rows_tpr);
+                                                             static_cast<double*>(p->rows_ws), p->rows_R, p->rows_tpr, p->rows_tpl, p->rows_cp);
   ba_tick(p, SFM_K_SCHUR, false, s);
   ba_tick(p, SFM_K_REDUCE, true, s);       // closed by the caller behind the camera-accumulator reduce
   ba_schur_rows_reduce_kernel<<<dim3((d.P + 255) / 256, d.P, 4), 256, 0, s>>>(d, static_cast<const double*>(p->rows_ws), p->rows_first,
