@@ -201,7 +201,8 @@ int ba_rows_plan(sfm_ba_problem* p) {
   // pitch follows the scene's visibility.  SFM_ROWS_PITCH8 = 0 / 1 forces it (A/B runs).
   static const int forced = [] { const char* e = getenv("SFM_ROWS_PITCH8"); return e ? (atoi(e) == 1 ? 8 : 7) : 0; }();
   const double visibility = (double)d.M / ((double)d.N * (double)d.V);
-  const int cp = forced ? forced : (visibility <= 0.25 ? 8 : 7);
+  int cp = forced ? forced : (visibility <= 0.25 ? 8 : 7);
+  if (cp == 8 && kRowsLdsBudget / ((size_t)7 * 8 * d.V * sizeof(double)) < 1) cp = 7;      // 349 ... 398 cameras: one camera still fits with pitch 7
   const int tpl = cp == 7 ? tpr : 8 * d.V;
   const int R = (int)std::min<size_t>((size_t)d.V, kRowsLdsBudget / ((size_t)7 * tpl * sizeof(double)));
   if (R < 1) return SFM_OK;                 // more than ~2800 cameras: the 18-camera tile kernel takes over
