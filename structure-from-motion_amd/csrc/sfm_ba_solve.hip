@@ -115,13 +115,16 @@ __device__ __forceinline__ void chol_trsm_cols(double (&c)[8], f64x2 (*xy)[64], 
 // INV = true: the same update for the identity rows, E[e][c] -= X[e][j-1] L[c][j-1]^T (e <= j-1 < c; rectangle, not
 // triangle).  E starts as the identity, so the block (e, c), c > e, is all zero until panel e contributes: the first
 // update (j - 1 == e) writes instead of accumulating and the buffer never needs clearing.
+// The super-tile is named by ABSOLUTE pair coordinates (block rows 2 sr, 2 sr + 1; block columns 2 sc, 2 sc + 1), so that the
+// same workgroup slot -- and with it the same XCD, see trail_pick -- updates a block in every column step.
 template <bool INV>
 __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, int sr, int sc) {
   const int nbk = d.nbk;
   double* red = d.red;
   double* rhs = d.red + red_rhs_off(nbk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = (INV ? 0 : j + 1) + 2 * sr + (wave >> 1), c = j + 1 + 2 * sc + (wave & 1);
+  const int r = 2 * sr + (wave >> 1), c = 2 * sc + (wave & 1);
+  if (c < j + 1) return;
   if (INV) { if (!(c <= nbk - 1 && r <= j - 1)) return; }
   else if (!(c <= nbk - 1 && r >= c && r <= nbk)) return;
   const bool is_rhs = !INV && r == nbk;
@@ -168,34 +171,91 @@ __device__ __forceinline__ void chol_trailing_supertile(const BaDev& d, int j, i
   }
 }
 
+// XCD-affine placement of the trailing work (round 4).  Workgroups are dealt round-robin to the 8 XCDs and an XCD's L2 keeps
+// the lines a launch touched for the next launch on the stream (tools/microbench_l2_across_launches.hip: a 16 MB
+// read-modify-write pass takes 1.4 us when the same XCD made the previous pass, 9 us when another did).  A trailing block is
+// read-modified-written in every column step until its own column comes up, so its super-tile (absolute pair coordinates
+// (R, C)) always goes to XCD (R + C) % 8: the trailing region of a step's grid is 8 x slots workgroups, workgroup
+// 8 slot + x takes the slot-th super-tile of XCD x in the enumeration below (or leaves at once).  At 200 cameras the
+// read-modify-write traffic of the trailing blocks was 90 us of the 411 us solve (profiles/r4/ablate_trailing_c4share.txt).
+// trail_pick: S-part, super-tiles (R >= C) with block columns >= j + 1 (C >= (j+1)/2), rows up to the rhs row nbk.
+__host__ __device__ inline bool trail_pick(int nbk, int j, int x, int slot, int* R_out, int* C_out, int* count_out) {
+  const int cmin = (j + 1) / 2, cmax = (nbk - 1) / 2, rmax = nbk / 2;
+  int count = 0;
+  for (int C = cmin; C <= cmax; ++C) {
+    const int first = C + ((x - 2 * C) % 8 + 8) % 8;          // smallest R >= C with (R + C) % 8 == x
+    if (first > rmax) continue;
+    const int n = (rmax - first) / 8 + 1;
+    if (slot >= 0 && slot < count + n) { *R_out = first + 8 * (slot - count); *C_out = C; return true; }
+    count += n;
+  }
+  if (count_out) *count_out = count;
+  return false;
+}
+// inv_pick: identity rows, pairs E (block rows 2E, 2E + 1 <= j - 1) x pairs C (block columns j + 1 .. nbk - 1).
+__host__ __device__ inline bool inv_pick(int nbk, int j, int x, int slot, int* E_out, int* C_out, int* count_out) {
+  const int cmin = (j + 1) / 2, cmax = (nbk - 1) / 2, emax = (j - 1) / 2;
+  int count = 0;
+  if (j >= 1 && cmin <= cmax) {
+    for (int E = 0; E <= emax; ++E) {
+      const int first = cmin + ((x - E - cmin) % 8 + 8) % 8;  // smallest C >= cmin with (E + C) % 8 == x
+      if (first > cmax) continue;
+      const int n = (cmax - first) / 8 + 1;
+      if (slot >= 0 && slot < count + n) { *E_out = E; *C_out = first + 8 * (slot - count); return true; }
+      count += n;
+    }
+  }
+  if (count_out) *count_out = count;
+  return false;
+}
+// slots per XCD of the two trailing regions of step j (host: grid size; the kernel gets them as arguments)
+struct StepSlots { int trail, itrail; };      // workgroup slots per XCD of the two trailing regions of a step's grid
+inline StepSlots step_slots(int nbk, int j, bool with_inv) {
+  StepSlots z{0, 0};
+  int r = 0, c = 0;
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    if (j > 0) { (void)trail_pick(nbk, j, x, -1, &r, &c, &n); z.trail = n > z.trail ? n : z.trail; }
+    n = 0;
+    if (with_inv && j > 0) { (void)inv_pick(nbk, j, x, -1, &r, &c, &n); z.itrail = n > z.itrail ? n : z.itrail; }
+  }
+  return z;
+}
+
 // Workgroup roles of column step j (with_inv = the identity rows are carried: dp = X y replaces the back substitution):
 //   [0, ncol)                 column role of block rows j .. nbk (nbk = the rhs row)
-//   [.., + nst)               trailing super-tiles (sr >= sc) of the blocks right of column j
-//   [.., + j)                 column role of the identity rows e = 0 .. j-1:  X[e][j] = (E[e][j] - X[e][j-1] L[j][j-1]^T) L_d^-T
-//   [.., + ceil(j/2) * ncs)   trailing super-tiles of the identity rows
-__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda, int with_inv) {
-  constexpr int kSq = NB * (NB + 1);
-  __shared__ __attribute__((aligned(16))) double arena[2 * kSq + (NB / 2) * 64 * 2 + 2];
+//   [.., + j)                 (with_inv) column role of the identity rows e = 0 .. j-1:  X[e][j] = (E[e][j] - X[e][j-1] L[j][j-1]^T) L_d^-T
+//   padding up to a multiple of 8, then, XCD-affine (trail_pick / inv_pick: workgroup 8 slot + x):
+//   [.., + 8 slots.trail)     trailing super-tiles of the blocks right of column j
+//   [.., + 8 slots.itrail)    trailing super-tiles of the identity rows
+// (The column roles stay first in the grid, in row order: placing them on the XCD that last updated their block as well was
+//  measured slower -- solve 369 vs 360 us at the C4 share, 85.5 vs 83.6 at C3.)
+constexpr int kCholSq = NB * (NB + 1);
+constexpr int kCholArena = 2 * kCholSq + (NB / 2) * 64 * 2 + 2;      // doubles of LDS a column-role workgroup needs
+
+__device__ __forceinline__ void chol_step_body(const BaDev& d, int j, double lambda, int with_inv, int role_in, double* arena,
+                                               StepSlots slots) {
+  constexpr int kSq = kCholSq;
   const int P = d.P, nbk = d.nbk;
   const int ncol = nbk - j + 1;
-  const int srn = j > 0 ? (nbk - j + 1) / 2 : 0, nst = srn * (srn + 1) / 2;
-  int role = blockIdx.x;
+  const int ncolumn_roles = ncol + (with_inv ? j : 0);
+  int role = role_in;
   bool inv_row = false;
   if (role >= ncol) {
+    if (role >= ncolumn_roles) {
+      const int base = (ncolumn_roles + 7) & ~7;
+      int t = role - base;
+      if (t < 0) return;                                   // padding
+      int a = 0, b = 0;
+      if (t < 8 * slots.trail) {
+        if (trail_pick(nbk, j, t & 7, t >> 3, &a, &b, nullptr)) chol_trailing_supertile<false>(d, j, a, b);
+        return;
+      }
+      t -= 8 * slots.trail;
+      if (t < 8 * slots.itrail && inv_pick(nbk, j, t & 7, t >> 3, &a, &b, nullptr)) chol_trailing_supertile<true>(d, j, a, b);
+      return;
+    }
     role -= ncol;
-    if (role < nst) {
-      int t = role, sr = 0;
-      while (t > sr) { t -= sr + 1; ++sr; }
-      chol_trailing_supertile<false>(d, j, sr, t);
-      return;
-    }
-    role -= nst;
-    if (role >= j) {                       // identity rows, trailing
-      role -= j;
-      const int ncs = (nbk - 1 - j + 1) / 2;       // column pairs over c = j+1 .. nbk-1
-      if (ncs > 0) chol_trailing_supertile<true>(d, j, role / ncs, role % ncs);
-      return;
-    }
     inv_row = true;                        // identity rows, column role: role = e
   }
   // column roles are the launch's critical path (the dependent pivot chain): when a trailing workgroup shares the
@@ -211,7 +271,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
   const bool is_rhs = r == nbk;
   const bool fresh = inv_row && e_row == j - 1;           // E[e][j] is still all zero: nothing to load
   // diagnostic stamps (SFM_OPT_DEBUG bit 8): shader-clock reads of one column workgroup's phases
-  unsigned long long* stamp = (d.stamps && blockIdx.x == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
+  unsigned long long* stamp = (d.stamps && !inv_row && role == 1 && threadIdx.x == 0) ? d.stamps + 8 * j : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
   double* red = d.red;
   double* rhs = d.red + red_rhs_off(nbk);
@@ -281,7 +341,7 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
   const int row = lane & (NB - 1);
   {
     // four-wave elimination: this wave's eight columns of all 64 rows
-    unsigned long long* stamp3 = (d.stamps && blockIdx.x == 1 && tid == 192) ? d.stamps + 8 * j : nullptr;
+    unsigned long long* stamp3 = (d.stamps && !inv_row && role == 1 && tid == 192) ? d.stamps + 8 * j : nullptr;
     double c[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) c[u] = src[row][8 * wave + u];
@@ -314,6 +374,11 @@ __global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, doubl
     if (stamp3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp3[5] = __builtin_amdgcn_s_memtime(); }
     return;
   }
+}
+
+__global__ __launch_bounds__(256) void ba_chol_step_kernel(BaDev d, int j, double lambda, int with_inv, StepSlots slots) {
+  __shared__ __attribute__((aligned(16))) double arena[kCholArena];
+  chol_step_body(d, j, lambda, with_inv, blockIdx.x, arena, slots);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -703,12 +768,13 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   const bool with_inv = !(d.debug & 512) && nbk <= kInvRowsMaxNbk;
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
-    // trailing role (from the second step on): 64x64 super-tiles over block rows j+1 .. nbk x block columns
-    // j+1 .. nbk-1, lower part only
-    const int srn = j > 0 ? (nbk - j + 1) / 2 : 0;
-    // identity rows e < j: j column workgroups, ceil(j/2) x ceil((nbk-1-j)/2) trailing super-tiles
-    const int ninv = with_inv ? j + ((j + 1) / 2) * ((nbk - 1 - j + 1) / 2) : 0;
-    ba_chol_step_kernel<<<ncol + srn * (srn + 1) / 2 + ninv, 256, 0, s>>>(d, j, lambda, with_inv ? 1 : 0);
+    // behind the column roles (+ the j column roles of the identity rows), padded to a multiple of 8: the trailing super-tiles
+    // of S and of the identity rows, 8 x slots workgroups each, XCD-affine (trail_pick / inv_pick)
+    const StepSlots z = step_slots(nbk, j, with_inv);
+    const int ncolumn_roles = ncol + (with_inv ? j : 0);
+    const int trailing = 8 * (z.trail + z.itrail);
+    const int grid = trailing > 0 ? ((ncolumn_roles + 7) & ~7) + trailing : ncolumn_roles;
+    ba_chol_step_kernel<<<grid, 256, 0, s>>>(d, j, lambda, with_inv ? 1 : 0, z);
   }
   if (with_inv) {
     ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
