@@ -75,6 +75,9 @@ struct BaDev {
   double* xinv = nullptr;   // [nbk (nbk + 1) / 2 blocks] X = L^-T, block (e, c >= e) at red_blk_base(c, e): the identity carried
                             // through the column steps as extra block rows (sfm_ba_solve.hip); dp = X y is one launch
   int* sync_ctr = nullptr;  // [1] workgroups of ba_inv_apply that have stored their part of dp (self-resetting)
+  unsigned* flow = nullptr; // [flow_words(nbk)] epoch / arrival / abort words and one flag per block of the data-flow solve (sfm_ba_flow.h); null beyond kFlowMaxNbk
+  const void* flow_tasks = nullptr;  // [flow_ntasks] FlowTask table of the data-flow solve, sorted by column
+  int flow_ntasks = 0;
   int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (diagnostic stamps, code-path switches)
   int* status = nullptr;    // [2] first failure code, camera index
   int* sinfo = nullptr;     // [4] structure check: first failure code, its index, longest track, unused
@@ -192,6 +195,7 @@ void ba_graph_drop(sfm_ba_problem* p); // forget the captured iteration bodies
 int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirks);
 bool ba_can_fuse(const sfm_ba_problem* p);
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda);      // sfm_ba_solve.hip: factor, solve, update cameras
+int ba_flow_setup(sfm_ba_problem* p);      // sfm_ba_solve.hip: flag words and task table of the data-flow solve (2 <= nbk <= kFlowMaxNbk)
 int comm_all_reduce_f64(sfm_comm* comm, double* buf, size_t count, hipStream_t s);      // sfm_comm.hip
 int comm_attach(sfm_comm* comm, int delta);      // a problem takes (+1) / gives back (-1) its hold on a communicator
 void ba_enqueue_residual_jacobian(sfm_ba_problem* p, int quirks, double* r, double* Jp, double* Jx);

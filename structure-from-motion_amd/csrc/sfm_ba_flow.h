@@ -1,0 +1,557 @@
+// sfm_ba_flow.h — the reduced camera solve as ONE persistent data-flow launch (included by sfm_ba_solve.hip, which
+// defines chol_trsm_cols and the operand layouts this file builds on).
+//
+// Why: the column steps of ba_chol_step are a chain of nbk dependent launches; a step is 0.7 us of launch, 1.5 us of
+// operand wait + previous-panel update, 3.35 us of elimination and 0.3 us of stores (profiles/r4/probe_solve.json) — half of it
+// is the round trip of the diagonal block through L2 and the launch boundary.  Here ONE workgroup (the chain) keeps
+// everything the pivot chain depends on in its own LDS and never leaves it: per block column j it eliminates [D_j; I]
+// (chol_trsm_cols: L_jj and X_j = L_jj^-T in one instruction stream), forms L[j+1][j] = T W_j^T and D_j+1 -= L L^T on the
+// matrix pipe out of LDS, and goes on.  Everything else — the blocks of L more than two block rows below the diagonal, the
+// right-hand side, the identity rows that leave X = L^-T behind for ba_inv_apply — is plain matrix-pipe work: one TASK per
+// block, LEFT-looking (S_ik - sum_m L[i][m] L[k][m]^T, then the product with W_k = L_kk^-1), dealt to the other workgroups
+// of the launch in column order.  Blocks travel through global memory: write-through (sc1) stores, one flag word per block,
+// sc1 loads on the consuming side (MI355X_MICROARCH.md, inter-workgroup visibility; every workgroup of this launch owns its
+// CU: 105 KB of LDS).
+//
+// Who computes what (the chain keeps the two sub-diagonals to itself):
+//   chain, step j:   elimination waves (0-3): [D_j; I] -> X_j -> xinv(j, j), W_j = X_j^T -> ldiag[j]; then
+//                    L[j+1][j] = T W_j^T (TRSM as a product), D_j+1 -= L[j+1][j] L[j+1][j]^T.
+//                    preparation waves (4-7), concurrently with the elimination, row r = j+1: take over the blocks
+//                    (r, r-2), (r, r-1), (r, r), L[r][r-2] = T W_j-1^T, and apply columns r-3 / r-2 to (r, r-1) and column
+//                    r-2 to (r, r).
+//   tasks of block row i >= 3:  L[i][k] for k <= i-4; the "closer" L[i][i-3] together with the hand-over blocks (i, i-2) and
+//                    (i, i) through column i-3 (sums through column i-4 formed before W_i-3 exists, the last terms out of LDS);
+//                    the hand-over block (i, i-1) through column i-4 — levels chosen so that no hand-over waits for a block
+//                    the chain publishes later than W_i-3.
+//   tasks of the rhs row and of the identity rows e = 0 .. nbk-2: the same recurrence with their own blocks.
+// Every block is produced by exactly one task with a fixed summation order: the result does not depend on timing or placement.
+// All products are formed TRANSPOSED (the 16x16x4 accumulator layout of M^T is the operand layout of M: rows lk + 4g), so a
+// block goes accumulator -> k-interleaved block (red_lblk_off) with two 16-byte stores per tile and comes back as an A or
+// B operand with four 16-byte loads, in LDS and in global memory alike.
+#pragma once
+
+namespace sfm {
+
+constexpr int kFlowMaxNbk = 16;      // one poll covers a row of up to 16 flags (73 cameras)
+constexpr int kFlowHdr = 16;         // header words of BaDev::flow: [0] epoch of the last finished solve, [1] workgroups done, [2] abort
+constexpr unsigned kFlowSpinLimit = 4000000u;   // polls (~0.5-1 us each) before a wait gives up and the solve reports SFM_E_HIP
+__host__ __device__ inline int flow_fl(int nbk, int i, int k) { return kFlowHdr + i * nbk + k; }                      // L[i][k] published
+__host__ __device__ inline int flow_fx(int nbk, int e, int m) { return kFlowHdr + nbk * nbk + e * nbk + m; }          // X[e][m] published
+__host__ __device__ inline int flow_fw(int nbk, int k) { return kFlowHdr + 2 * nbk * nbk + k; }                       // W_k published
+__host__ __device__ inline int flow_fy(int nbk, int k) { return kFlowHdr + 2 * nbk * nbk + nbk + k; }                 // y_k published
+__host__ __device__ inline int flow_fh(int nbk, int i, int t) { return kFlowHdr + 2 * nbk * nbk + 2 * nbk + 3 * i + t; }   // hand-over block (i, i-2+t)
+__host__ __device__ inline int flow_words(int nbk) { return kFlowHdr + 2 * nbk * nbk + 5 * nbk; }
+
+// task table (host-built once per problem, sorted by the column a task waits for last)
+enum { FLOW_T1 = 0, FLOW_CLOSER = 1, FLOW_H1 = 2, FLOW_RHS = 3, FLOW_IDENT = 4 };
+struct FlowTask { int type, i, k, key; };
+
+// LDS carve (doubles)
+constexpr int FS_DM = 0;                  // [32][33] D_j, row-major (elimination: lane = row)
+constexpr int FS_XM = 1056;               // [32][33] X_j rows as the elimination leaves them
+constexpr int FS_XY = 2112;               // f64x2[16][64] published pivots of chol_trsm_cols
+constexpr int FS_W = 4160;                // [2][1024] W_j, W_j-1 (k-interleaved)
+constexpr int FS_LA = 6208;               // [2][1024] L[j+1][j] of this and the previous step
+constexpr int FS_LB = 8256;               // [2][1024] L[r][r-2] of this and the previous step
+constexpr int FS_B = 10304;               // [3][1024] the row being taken over: (r, r-2), (r, r-1), (r, r); tasks: T and L
+constexpr int FS_INT = 13376;             // ints: [0] elimination flag, [1] preparation-group barrier counter
+constexpr int FS_TOTAL = 13384;
+constexpr size_t kFlowLdsBytes = FS_TOTAL * sizeof(double);
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct FlowBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ FlowBuf flow_buf(const void* base) {
+  return FlowBuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)};
+}
+// write-through / L1-bypassing 16-byte accesses (buffer_load / store_dwordx4 ... sc1); offsets in doubles
+__device__ __forceinline__ f64x2 ld2_sc1(FlowBuf b, size_t off) {
+  return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)(off * 8), 0, 16));
+}
+__device__ __forceinline__ void st2_sc1(FlowBuf b, size_t off, f64x2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b.r, (int)(off * 8), 0, 16);
+}
+__device__ __forceinline__ void flow_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// operand tile `tile` (rows 16 tile .. +15) of a k-interleaved block: from global memory (sc1) / from LDS
+__device__ __forceinline__ void op_sc1(FlowBuf b, size_t blk, int tile, int lr, int lk, double (&o)[8]) {
+  const size_t p = blk + lk * 64 + (16 * tile + lr) * 2;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const f64x2 v = ld2_sc1(b, p + 256 * m); o[2 * m] = v.x; o[2 * m + 1] = v.y; }
+}
+__device__ __forceinline__ void op_lds(const double* blk, int tile, int lr, int lk, double (&o)[8]) {
+  const double* p = blk + lk * 64 + (16 * tile + lr) * 2;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const f64x2 v = *reinterpret_cast<const f64x2*>(p + 256 * m); o[2 * m] = v.x; o[2 * m + 1] = v.y; }
+}
+// the rhs row as a block with one valid row: y_m sits at rhs[32 m ..]
+__device__ __forceinline__ void op_rhs_sc1(const double* seg, bool row0, int lk, double (&o)[8]) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) o[ks] = row0 ? __hip_atomic_load(seg + 4 * ks + lk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+}
+// acc(kappa, a) += sum_k A(kappa, k) B(a, k): A, B operand tiles of two k-interleaved blocks
+__device__ __forceinline__ void mfma8(f64x4& acc, const double (&a)[8], const double (&b)[8]) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+}
+// Accumulator tile (sx, sy) of M^T -- register g of lane (lr, lk) is M(a = 16 sy + lr, kappa = 16 sx + lk + 4 g) -- inside the
+// k-interleaved block of M: g = 0, 1 at ctile_off, g = 2, 3 256 doubles further.
+__device__ __forceinline__ int ctile_off(int sx, int sy, int lr, int lk) { return 2 * sx * 256 + lk * 64 + 2 * (16 * sy + lr); }
+__device__ __forceinline__ void ctile_st_lds(double* blk, int off, const f64x4& v) {
+  *reinterpret_cast<f64x2*>(blk + off) = f64x2{v[0], v[1]};
+  *reinterpret_cast<f64x2*>(blk + off + 256) = f64x2{v[2], v[3]};
+}
+__device__ __forceinline__ f64x4 ctile_ld_lds(const double* blk, int off) {
+  const f64x2 p = *reinterpret_cast<const f64x2*>(blk + off), q = *reinterpret_cast<const f64x2*>(blk + off + 256);
+  return f64x4{p.x, p.y, q.x, q.y};
+}
+__device__ __forceinline__ void ctile_st_sc1(FlowBuf b, size_t blk, int off, const f64x4& v) {
+  st2_sc1(b, blk + off, f64x2{v[0], v[1]});
+  st2_sc1(b, blk + off + 256, f64x2{v[2], v[3]});
+}
+// tile (sx, sy) of S_blk^T from a row-major block of S (plain loads: nothing in this launch writes S before its reader has it)
+__device__ __forceinline__ f64x4 ctile_ld_S(const double* blk, int sx, int sy, int lr, int lk) {
+  const double* p = blk + (16 * sy + lr) * kNB + 16 * sx + lk;
+  return f64x4{p[0], p[4], p[8], p[12]};
+}
+
+// Waiting.  Lane 0.. poll flags, lane 63 the abort word, relaxed agent-scope loads (sc1).  After a give-up (a sibling never
+// scheduled, or the spin limit reached) every further wait returns at once: the control flow -- and with it the number of barriers
+// every wave passes -- stays what it is, the results are garbage and d.status says so.
+struct FlowWait {
+  unsigned* flow; unsigned epoch; int* status; bool dead;
+  __device__ __forceinline__ void give_up() {
+    if ((threadIdx.x & 63) == 0) { __hip_atomic_store(flow + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); report_status(status, SFM_E_HIP, -2); }
+    dead = true;
+  }
+  // up to four single flags at once
+  __device__ __forceinline__ void wait(int i0, int i1 = -1, int i2 = -1, int i3 = -1) {
+    if (dead) return;
+    const int lane = threadIdx.x & 63;
+    const int mine = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : lane == 3 ? i3 : (lane == 63 ? 2 : -1);
+    for (unsigned spins = 0;; ++spins) {
+      unsigned v = epoch;
+      if (mine >= 0) v = __hip_atomic_load(flow + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long miss = __ballot(lane < 4 && mine >= 0 && v != epoch);
+      if (!miss) break;
+      if (__builtin_amdgcn_readlane(v, 63) != 0 || spins > kFlowSpinLimit) { give_up(); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the compiler from hoisting loads above the poll
+  }
+  // Terms m0 .. m0+n-1 of a row sum; term t is ready when flag idx[q] + t carries the epoch for every one of the nrows <= 3 flag
+  // rows (row q polled by lanes 16 q .. 16 q + 15).  Waits until `need` leading terms are ready, returns how many are.
+  __device__ __forceinline__ int wait_terms(int idxa, int idxb, int idxc, int nrows, int n, int need) {
+    if (dead || n <= 0) return n;
+    const int lane = threadIdx.x & 63, q = lane >> 4, t = lane & 15;
+    const bool mine = q < nrows && t < n;
+    const int idx = (q == 0 ? idxa : q == 1 ? idxb : idxc) + t;
+    int have = 0;
+    for (unsigned spins = 0;; ++spins) {
+      unsigned v = epoch;
+      if (mine) v = __hip_atomic_load(flow + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned ab = 0;
+      if (lane == 63) ab = __hip_atomic_load(flow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long miss = __ballot(mine && v != epoch);
+      const unsigned m16 = (unsigned)((miss | (miss >> 16) | (miss >> 32)) & 0xffffu);
+      have = m16 ? __builtin_ctz(m16) : n;
+      if (have >= need) break;
+      if (__builtin_amdgcn_readlane(ab, 63) != 0 || spins > kFlowSpinLimit) { give_up(); have = n; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return have;
+  }
+};
+__device__ __forceinline__ void flow_publish(unsigned* flow, int idx, unsigned epoch) {
+  __hip_atomic_store(flow + idx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// barrier of the four preparation waves alone (the elimination waves run beside them and meet no barrier): every wave
+// finishes its LDS writes, one lane arrives on an LDS counter, all spin until the round's arrivals are in
+__device__ __forceinline__ void flow_group_sync(int* ctr, int& target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  target += 4;
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct FlowCtx {
+  FlowBuf red, xinv, ldiag;
+  double* redp; double* rhs;      // plain views (S blocks, the rhs segment)
+  unsigned* flow; unsigned epoch; int nbk;
+  double* sm; int* smi;
+  int lane, lr, lk, gw, sx, sy;
+  FlowWait w;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tasks (four waves, wave (sx, sy) owns accumulator tile (sx, sy)).
+// A row sum: acc(kappa, a) += sum_{m = m0}^{m1 - 1} L[arow][m](kappa, .) . own[m](a, .), terms taken in order, up to four of
+// them loaded at a time as soon as their flags are up.
+// OWN 0: a block row of L (red);  1: the rhs row (y_m);  2: identity row `own` (xinv).
+// ---------------------------------------------------------------------------------------------
+template <int OWN>
+__device__ __forceinline__ void flow_own_operand(FlowCtx& c, int own, int m, double (&b)[8]) {
+  if (OWN == 0) op_sc1(c.red, red_blk_base(own, m), c.sy, c.lr, c.lk, b);
+  else if (OWN == 1) op_rhs_sc1(c.rhs + m * kNB, c.sy == 0 && c.lr == 0, c.lk, b);
+  else op_sc1(c.xinv, red_blk_base(m, own), c.sy, c.lr, c.lk, b);
+}
+template <int OWN>
+__device__ __forceinline__ int flow_own_flag(const FlowCtx& c, int own, int m) {
+  return OWN == 0 ? flow_fl(c.nbk, own, m) : OWN == 1 ? flow_fy(c.nbk, m) : flow_fx(c.nbk, own, m);
+}
+template <int OWN>
+__device__ __forceinline__ void flow_row_sum(FlowCtx& c, f64x4& acc, int arow, int own, int m0, int m1) {
+  int ready = m0;
+  for (int m = m0; m < m1;) {
+    if (m >= ready)
+      ready = m0 + c.w.wait_terms(flow_fl(c.nbk, arow, m0), flow_own_flag<OWN>(c, own, m0), 0, (OWN == 0 && arow == own) ? 1 : 2, m1 - m0, m - m0 + 1);
+    const int n = min(ready - m, 4);
+    double a[4][8], b[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < n) { op_sc1(c.red, red_blk_base(arow, m + q), c.sx, c.lr, c.lk, a[q]); flow_own_operand<OWN>(c, own, m + q, b[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < n) mfma8(acc, a[q], b[q]);
+    m += n;
+  }
+}
+
+// second half of a plain task: T^T (accumulator layout) -> LDS -> L^T = W_k T^T -> its k-interleaved block in global memory
+template <int OWN>
+__device__ __forceinline__ void flow_finish(FlowCtx& c, const f64x4& t, int own, int k) {
+  double* Tx = c.sm + FS_B;
+  const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk);
+  ctile_st_lds(Tx, coff, t);
+  __syncthreads();
+  c.w.wait(flow_fw(c.nbk, k));
+  double a[8], b[8];
+  op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
+  op_lds(Tx, c.sy, c.lr, c.lk, b);
+  f64x4 o = {0, 0, 0, 0};
+  mfma8(o, a, b);
+  if (OWN == 0) ctile_st_sc1(c.red, red_blk_base(own, k), coff, o);
+  else if (OWN == 2) ctile_st_sc1(c.xinv, red_blk_base(k, own), coff, o);
+  else if (c.sy == 0 && c.lr == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) __hip_atomic_store(c.rhs + k * kNB + 16 * c.sx + c.lk + 4 * g, o[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  flow_drain();
+  __syncthreads();      // every wave's stores are in memory (and Tx is free again)
+  if (threadIdx.x == 0) flow_publish(c.flow, flow_own_flag<OWN>(c, own, k), c.epoch);
+}
+
+__device__ __forceinline__ void flow_task_t1(FlowCtx& c, int i, int k) {
+  const f64x4 s = ctile_ld_S(c.redp + red_blk_base(i, k), c.sx, c.sy, c.lr, c.lk);
+  f64x4 acc = {0, 0, 0, 0};
+  flow_row_sum<0>(c, acc, k, i, 0, k);
+  flow_finish<0>(c, s - acc, i, k);
+}
+
+// hand-over block (i, i-1) through column i-4
+__device__ __forceinline__ void flow_task_h1(FlowCtx& c, int i) {
+  const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk);
+  const f64x4 s = ctile_ld_S(c.redp + red_blk_base(i, i - 1), c.sx, c.sy, c.lr, c.lk);
+  f64x4 acc = {0, 0, 0, 0};
+  flow_row_sum<0>(c, acc, i - 1, i, 0, i - 3);
+  __syncthreads();      // every wave has its part of S before any wave overwrites the block
+  ctile_st_sc1(c.red, red_blk_base(i, i - 1), coff, s - acc);
+  flow_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) flow_publish(c.flow, flow_fh(c.nbk, i, 1), c.epoch);
+}
+
+// L[i][i-3] and the hand-over blocks (i, i-2), (i, i) through column i-3: the three sums through column i-4 share the operand
+// tiles of row i and are complete before W_i-3 exists; what W_i-3 releases is one product, an LDS round trip and two terms.
+__device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
+  const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk), k = i - 3, nbk = c.nbk;
+  const f64x4 sT = ctile_ld_S(c.redp + red_blk_base(i, k), c.sx, c.sy, c.lr, c.lk);
+  const f64x4 s0 = ctile_ld_S(c.redp + red_blk_base(i, i - 2), c.sx, c.sy, c.lr, c.lk);
+  const f64x4 s2 = ctile_ld_S(c.redp + red_blk_base(i, i), c.sx, c.sy, c.lr, c.lk);
+  f64x4 accT = {0, 0, 0, 0}, acc0 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  int ready = 0;
+  for (int m = 0; m < k;) {
+    if (m >= ready) ready = c.w.wait_terms(flow_fl(nbk, k, 0), flow_fl(nbk, i - 2, 0), flow_fl(nbk, i, 0), 3, k, m + 1);
+    const int n = min(ready - m, 2);
+    double b[2][8], at[2][8], a0[2][8], a2[2][8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < n) {
+        op_sc1(c.red, red_blk_base(i, m + q), c.sy, c.lr, c.lk, b[q]);
+        op_sc1(c.red, red_blk_base(k, m + q), c.sx, c.lr, c.lk, at[q]);
+        op_sc1(c.red, red_blk_base(i - 2, m + q), c.sx, c.lr, c.lk, a0[q]);
+        op_sc1(c.red, red_blk_base(i, m + q), c.sx, c.lr, c.lk, a2[q]);
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < n) { mfma8(accT, at[q], b[q]); mfma8(acc0, a0[q], b[q]); mfma8(acc2, a2[q], b[q]); }
+    m += n;
+  }
+  double* Tx = c.sm + FS_B;
+  double* Lx = c.sm + FS_B + kBlk;
+  ctile_st_lds(Tx, coff, sT - accT);
+  __syncthreads();
+  c.w.wait(flow_fw(nbk, k), flow_fl(nbk, i - 2, k));
+  double a[8], b[8], a0[8];
+  op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
+  op_sc1(c.red, red_blk_base(i - 2, k), c.sx, c.lr, c.lk, a0);
+  op_lds(Tx, c.sy, c.lr, c.lk, b);
+  f64x4 o = {0, 0, 0, 0};
+  mfma8(o, a, b);
+  ctile_st_sc1(c.red, red_blk_base(i, k), coff, o);
+  ctile_st_lds(Lx, coff, o);
+  __syncthreads();
+  op_lds(Lx, c.sy, c.lr, c.lk, b);
+  op_lds(Lx, c.sx, c.lr, c.lk, a);
+  mfma8(acc0, a0, b);
+  mfma8(acc2, a, b);
+  ctile_st_sc1(c.red, red_blk_base(i, i - 2), coff, s0 - acc0);
+  ctile_st_sc1(c.red, red_blk_base(i, i), coff, s2 - acc2);
+  flow_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    flow_publish(c.flow, flow_fl(nbk, i, k), c.epoch);
+    flow_publish(c.flow, flow_fh(nbk, i, 0), c.epoch);
+    flow_publish(c.flow, flow_fh(nbk, i, 2), c.epoch);
+  }
+}
+
+__device__ __forceinline__ void flow_task_rhs(FlowCtx& c, int k) {
+  f64x4 s = {0, 0, 0, 0};
+  if (c.sy == 0 && c.lr == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s[g] = c.rhs[k * kNB + 16 * c.sx + c.lk + 4 * g];
+  }
+  f64x4 acc = {0, 0, 0, 0};
+  flow_row_sum<1>(c, acc, k, 0, 0, k);
+  flow_finish<1>(c, s - acc, 0, k);
+}
+
+__device__ __forceinline__ void flow_task_ident(FlowCtx& c, int e, int k) {
+  f64x4 acc = {0, 0, 0, 0};
+  flow_row_sum<2>(c, acc, k, e, e, k);
+  flow_finish<2>(c, -acc, e, k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain.  512 threads: waves 0-3 eliminate, waves 4-7 prepare the next row meanwhile.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double lambda) {
+  const int nbk = c.nbk, P = d.P;
+  const int tid = threadIdx.x, lane = c.lane, grp = tid >> 8;
+  const int sx = c.sx, sy = c.sy, lr = c.lr, lk = c.lk, gw = c.gw;
+  double* sm = c.sm;
+  double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_DM);
+  double(*Xm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_XM);
+  f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(sm + FS_XY);
+  int* eflag = c.smi;
+  int* pctr = c.smi + 1;
+  int ptarget = 0;
+  const int coff = ctile_off(sx, sy, lr, lk);
+  unsigned long long* stamp = (d.stamps && (tid == 0 || tid == 256)) ? d.stamps + (tid == 0 ? 0 : 512) : nullptr;
+
+  // D(a, kappa) of diagonal block `blk` from accumulator tile (sx, sy) of D^T: + lambda, identity on the padding
+  auto put_d = [&](int blk, const f64x4& v) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int a = 16 * sy + lr, kap = 16 * sx + lk + 4 * g;
+      const bool ok_a = blk * NB + a < P, ok_k = blk * NB + kap < P;
+      double t = (ok_a && ok_k) ? v[g] : 0.0;
+      if (a == kap) t = ok_a ? t + lambda : 1.0;
+      Dm[a][kap] = t;
+    }
+  };
+  if (grp == 0) put_d(0, ctile_ld_S(c.redp + red_blk_base(0, 0), sx, sy, lr, lk));
+  if (tid == 0) { eflag[0] = 0; pctr[0] = 0; }
+  __syncthreads();
+
+  for (int j = 0; j < nbk; ++j) {
+    const int r = j + 1;
+    const bool has_r = r < nbk;
+    double* Wcur = sm + FS_W + (j & 1) * kBlk;
+    const double* Wprev = sm + FS_W + ((j & 1) ^ 1) * kBlk;
+    double* LAcur = sm + FS_LA + (j & 1) * kBlk;
+    const double* LAprev = sm + FS_LA + ((j & 1) ^ 1) * kBlk;
+    double* LBcur = sm + FS_LB + (j & 1) * kBlk;
+    const double* LBprev = sm + FS_LB + ((j & 1) ^ 1) * kBlk;
+    double* B0 = sm + FS_B, *B1 = sm + FS_B + kBlk, *B2 = sm + FS_B + 2 * kBlk;
+    if (stamp) stamp[8 * j + 0] = __builtin_amdgcn_s_memtime();
+    if (grp == 0) {
+      // ---- elimination of [D_j; I]
+      const int row = lane & (NB - 1);
+      double cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cc[u] = lane < NB ? Dm[row][8 * gw + u] : ((row == 8 * gw + u) ? 1.0 : 0.0);
+      chol_trsm_cols(cc, xy, eflag, lane, gw);
+      if (lane >= NB) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = 8 * gw + u; cc[u] = (k >= row) ? cc[u] : 0.0; Xm[row][k] = cc[u]; }
+        // X_j = the identity row's first block X[j][j], in the operand layout (what ba_inv_apply and the tasks of identity row j read)
+        const size_t out = red_blk_base(j, j) + gw * 256 + row * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st2_sc1(c.xinv, out + q * 64, f64x2{cc[q], cc[q + 4]});
+      }
+      flow_drain();
+    } else if (has_r) {
+      // ---- preparation of row r = j + 1 beside the elimination
+      double a[8], b[8];
+      if (r >= 3) {
+        c.w.wait(flow_fh(nbk, r, 0), flow_fh(nbk, r, 1), flow_fh(nbk, r, 2));
+        if (stamp) stamp[8 * j + 5] = __builtin_amdgcn_s_memtime();
+        const int u0 = tid - 256;
+        f64x2 v[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) v[t][h] = ld2_sc1(c.red, red_blk_base(r, r - 2 + t) + 2 * (u0 + 256 * h));
+        op_sc1(c.red, red_blk_base(r, r - 3), sy, lr, lk, b);      // L[r][r-3]: published before the hand-over blocks
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) *reinterpret_cast<f64x2*>(B0 + t * kBlk + 2 * (u0 + 256 * h)) = v[t][h];
+      } else {
+        if (r == 2) ctile_st_lds(B0, coff, ctile_ld_S(c.redp + red_blk_base(2, 0), sx, sy, lr, lk));
+        ctile_st_lds(B1, coff, ctile_ld_S(c.redp + red_blk_base(r, r - 1), sx, sy, lr, lk));
+        ctile_st_lds(B2, coff, ctile_ld_S(c.redp + red_blk_base(r, r), sx, sy, lr, lk));
+      }
+      flow_group_sync(pctr, ptarget);
+      if (r >= 3) {
+        // (r, r-1) -= L[r][r-3] L[r-1][r-3]^T
+        op_lds(LBprev, sx, lr, lk, a);
+        f64x4 acc = {0, 0, 0, 0};
+        mfma8(acc, a, b);
+        ctile_st_lds(B1, coff, ctile_ld_lds(B1, coff) - acc);
+      }
+      if (r >= 2) {
+        // L[r][r-2]^T = W_j-1 T^T
+        op_lds(Wprev, sx, lr, lk, a);
+        op_lds(B0, sy, lr, lk, b);
+        f64x4 o = {0, 0, 0, 0};
+        mfma8(o, a, b);
+        ctile_st_lds(LBcur, coff, o);
+        ctile_st_sc1(c.red, red_blk_base(r, r - 2), coff, o);
+        flow_group_sync(pctr, ptarget);
+        // (r, r-1) -= L[r][r-2] L[r-1][r-2]^T ; (r, r) -= L[r][r-2] L[r][r-2]^T
+        op_lds(LBcur, sy, lr, lk, b);
+        op_lds(LAprev, sx, lr, lk, a);
+        f64x4 acc = {0, 0, 0, 0};
+        mfma8(acc, a, b);
+        ctile_st_lds(B1, coff, ctile_ld_lds(B1, coff) - acc);
+        if (gw != 2) {
+          op_lds(LBcur, sx, lr, lk, a);
+          f64x4 acc2 = {0, 0, 0, 0};
+          mfma8(acc2, a, b);
+          ctile_st_lds(B2, coff, ctile_ld_lds(B2, coff) - acc2);
+        }
+      }
+      flow_drain();
+      if (stamp) stamp[8 * j + 6] = __builtin_amdgcn_s_memtime();
+    }
+    __syncthreads();                                                  // B: X_j in Xm, row r prepared
+    if (stamp) stamp[8 * j + 1] = __builtin_amdgcn_s_memtime();
+    {
+      // W_j = X_j^T into the operand layout: LDS (this step's TRSM, the next step's preparation) and ldiag[j] (the tasks)
+      const int m = tid >> 7, lk2 = (tid >> 5) & 3, col = tid & 31, kap = 8 * m + lk2;
+      const f64x2 v = {Xm[kap][col], Xm[kap + 4][col]};
+      const int off = m * 256 + lk2 * 64 + 2 * col;
+      *reinterpret_cast<f64x2*>(Wcur + off) = v;
+      st2_sc1(c.ldiag, (size_t)j * kBlk + off, v);
+      flow_drain();
+    }
+    __syncthreads();                                                  // C
+    if (tid == 0) {
+      flow_publish(c.flow, flow_fw(nbk, j), c.epoch);
+      flow_publish(c.flow, flow_fx(nbk, j, j), c.epoch);
+      if (has_r && r >= 2) flow_publish(c.flow, flow_fl(nbk, r, r - 2), c.epoch);
+      eflag[0] = 0;
+    }
+    if (stamp) stamp[8 * j + 2] = __builtin_amdgcn_s_memtime();
+    if (!has_r) break;
+    if (grp == 0) {
+      // L[r][j]^T = W_j T^T
+      double a[8], b[8];
+      op_lds(Wcur, sx, lr, lk, a);
+      op_lds(B1, sy, lr, lk, b);
+      f64x4 o = {0, 0, 0, 0};
+      mfma8(o, a, b);
+      ctile_st_lds(LAcur, coff, o);
+      ctile_st_sc1(c.red, red_blk_base(r, j), coff, o);
+      flow_drain();
+    }
+    __syncthreads();                                                  // D
+    if (tid == 0) flow_publish(c.flow, flow_fl(nbk, r, j), c.epoch);
+    if (stamp) stamp[8 * j + 3] = __builtin_amdgcn_s_memtime();
+    if (grp == 0 && gw != 2) {
+      // D_r -= L[r][j] L[r][j]^T, lower tiles only
+      double a[8], b[8];
+      op_lds(LAcur, sx, lr, lk, a);
+      op_lds(LAcur, sy, lr, lk, b);
+      f64x4 acc = {0, 0, 0, 0};
+      mfma8(acc, a, b);
+      put_d(r, ctile_ld_lds(B2, coff) - acc);
+    }
+    __syncthreads();                                                  // A
+    if (stamp) stamp[8 * j + 4] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// Workgroup 0 is the chain; workgroup b >= 1 takes tasks b-1, b-1 + (grid-1), ... of the table (sorted by column: a task waits
+// only for tasks of earlier columns, so every workgroup's list can be run in order once all workgroups are resident).
+__global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda) {
+  extern __shared__ __attribute__((aligned(16))) double flow_sm[];
+  const int tid = threadIdx.x;
+  if (blockIdx.x != 0 && tid >= 256) return;      // tasks are run by four waves
+  FlowCtx c;
+  c.red = flow_buf(d.red); c.xinv = flow_buf(d.xinv); c.ldiag = flow_buf(d.ldiag);
+  c.redp = d.red; c.rhs = d.red + red_rhs_off(d.nbk);
+  c.flow = flow; c.nbk = d.nbk;
+  c.epoch = __hip_atomic_load(flow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  c.sm = flow_sm; c.smi = reinterpret_cast<int*>(flow_sm + FS_INT);
+  c.lane = tid & 63; c.lr = c.lane & 15; c.lk = c.lane >> 4;
+  c.gw = (tid >> 6) & 3; c.sx = c.gw >> 1; c.sy = c.gw & 1;
+  c.w = FlowWait{flow, c.epoch, d.status, false};
+  if (blockIdx.x == 0) {
+    flow_chain(c, d, lambda);
+  } else {
+    for (int t = blockIdx.x - 1; t < ntasks; t += gridDim.x - 1) {
+      const FlowTask tk = tasks[t];
+      switch (tk.type) {
+        case FLOW_T1: flow_task_t1(c, tk.i, tk.k); break;
+        case FLOW_CLOSER: flow_task_closer(c, tk.i); break;
+        case FLOW_H1: flow_task_h1(c, tk.i); break;
+        case FLOW_RHS: flow_task_rhs(c, tk.k); break;
+        default: flow_task_ident(c, tk.i, tk.k); break;
+      }
+    }
+  }
+  // the last workgroup to leave closes the epoch
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(flow + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+      __hip_atomic_store(flow + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flow + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flow, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// the task table of a problem with nbk block columns, in the order the workgroups take it
+inline std::vector<FlowTask> flow_build_tasks(int nbk) {
+  std::vector<FlowTask> t;
+  for (int i = 3; i < nbk; ++i) {
+    t.push_back(FlowTask{FLOW_CLOSER, i, i - 3, 8 * (i - 3) + 0});
+    t.push_back(FlowTask{FLOW_H1, i, i - 1, 8 * std::max(0, i - 4) + 1});
+    for (int k = 0; k <= i - 4; ++k) t.push_back(FlowTask{FLOW_T1, i, k, 8 * k + 2});
+  }
+  for (int k = 0; k < nbk; ++k) t.push_back(FlowTask{FLOW_RHS, 0, k, 8 * k + 3});
+  for (int e = 0; e + 1 < nbk; ++e)
+    for (int k = e + 1; k < nbk; ++k) t.push_back(FlowTask{FLOW_IDENT, e, k, 8 * k + 4});
+  std::stable_sort(t.begin(), t.end(), [](const FlowTask& x, const FlowTask& y) { return x.key < y.key; });
+  return t;
+}
+
+}  // namespace sfm

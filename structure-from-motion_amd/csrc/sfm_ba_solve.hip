@@ -752,6 +752,30 @@ __global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int
   if (stamp && wave == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp[4] = __builtin_amdgcn_s_memtime(); }
 }
 
+}  // namespace sfm
+#include "sfm_ba_flow.h"
+namespace sfm {
+
+int ba_flow_setup(sfm_ba_problem* p) {
+  BaDev& d = p->dev;
+  if (d.nbk < 2 || d.nbk > kFlowMaxNbk) return SFM_OK;
+  const std::vector<FlowTask> tasks = flow_build_tasks(d.nbk);
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&d.flow), sizeof(unsigned) * flow_words(d.nbk)));
+  void* tk = nullptr;
+  SFM_HIP(pool_alloc(&tk, sizeof(FlowTask) * std::max<size_t>(1, tasks.size())));
+  d.flow_tasks = tk;
+  d.flow_ntasks = (int)tasks.size();
+  SFM_HIP(hipMemsetAsync(d.flow, 0, sizeof(unsigned) * flow_words(d.nbk), p->stream));
+  // the table is pageable host memory that dies with this call: a synchronous copy
+  if (!tasks.empty()) SFM_HIP(hipMemcpy(tk, tasks.data(), sizeof(FlowTask) * tasks.size(), hipMemcpyHostToDevice));
+  static int attr_device = -1;
+  if (attr_device != ctx().device) {
+    SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsBytes));
+    attr_device = ctx().device;
+  }
+  return SFM_OK;
+}
+
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
@@ -766,6 +790,14 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   // (tools/time_solve_paths.py) 153 vs 198 us at nbk = 20, 293 vs 340 at 35, 422 vs 448 at 44, 643 vs 640 at 57,
   // 932 vs 910 at 75 -- used up to 52 block columns (V <= 237)
   const bool with_inv = !(d.debug & 512) && nbk <= kInvRowsMaxNbk;
+  // SFM_OPT_DEBUG bit 1024: column steps as separate launches where the data-flow launch would run
+  if (with_inv && d.flow != nullptr && !(d.debug & 1024)) {
+    const int grid = 1 + std::min(d.flow_ntasks, ctx().num_cus - 32);
+    ba_chol_flow_kernel<<<grid, 512, kFlowLdsBytes, s>>>(d, d.flow, static_cast<const FlowTask*>(d.flow_tasks), d.flow_ntasks, lambda);
+    ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
+    SFM_HIP(hipGetLastError());
+    return SFM_OK;
+  }
   for (int j = 0; j < nbk; ++j) {
     const int ncol = nbk - j + 1;                        // column role: block rows j .. nbk (nbk = the rhs row)
     // behind the column roles (+ the j column roles of the identity rows), padded to a multiple of 8: the trailing super-tiles

@@ -1,0 +1,45 @@
+"""Data-flow solve (sfm_ba_flow.h) against the column-step launches (SFM_OPT_DEBUG bit 1024) and the oracle on scenes of 9-70
+cameras; with `stamps` as the first argument: the chain's phase stamps at C3."""
+import importlib, json, os, sys, time
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
+sfm = importlib.import_module("structure-from-motion_amd"); native = sfm.native; native.init(0)
+
+def run(sc, uvn, dbg, iters, lam=5.0):
+    with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(native.OPT_DEBUG, dbg)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(lam, iters)
+        return prob.get_state()
+
+if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+    sc = sfm.scenes.make_config("C3", seed=0); uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(native.OPT_DEBUG, 8)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 4); native.synchronize()
+        raw = prob.debug_stamps(1024).astype(np.int64)
+    el, pr = raw[:128].reshape(16, 8), raw[512:640].reshape(16, 8)
+    t0 = el[0, 0]
+    for j in range(11):
+        print("step %2d  start %6d  elim+prep %5d  transpose %4d  trsm %4d  syrk %4d | prep: hand-over seen %6d, done %6d (rel. to step start)" % (
+            j, el[j, 0] - t0, el[j, 1] - el[j, 0], el[j, 2] - el[j, 1], el[j, 3] - el[j, 2], el[j, 4] - el[j, 3], pr[j, 5] - el[j, 0], pr[j, 6] - el[j, 0]))
+    print("chain total ticks", el[10, 2] - t0)
+    sys.exit(0)
+
+oracle = importlib.import_module("sfm_oracle")
+worst = 0.0
+for (V, N, vis, seed) in ((9, 300, 0.8, 1), (10, 400, 0.6, 2), (14, 500, 0.5, 3), (19, 600, 0.5, 4), (28, 600, 0.4, 5), (37, 700, 0.4, 6), (50, 900, 0.6, 7), (64, 900, 0.3, 8), (73, 900, 0.3, 9)):
+    sc = sfm.scenes.make_scene(V, N, vis, seed=seed); uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    t0 = time.time()
+    c_new, p_new = run(sc, uvn, 0, 2)
+    c_old, p_old = run(sc, uvn, 1024, 2)
+    oc, op = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    r_old = float(np.max(np.abs(c_new - c_old)) / np.max(np.abs(c_old)))
+    r_or = float(np.max(np.abs(c_new - oc)) / np.max(np.abs(oc)))
+    r_pt = float(np.max(np.abs(p_new - op)) / np.max(np.abs(op)))
+    worst = max(worst, r_or, r_pt)
+    print("V=%d nbk=%d: flow vs column steps %.2e, vs oracle cams %.2e pts %.2e  (%.1f s)" % (V, (7 * V + 31) // 32, r_old, r_or, r_pt, time.time() - t0), flush=True)
+print("worst", worst)
+sys.exit(0 if worst < 1e-9 else 1)
