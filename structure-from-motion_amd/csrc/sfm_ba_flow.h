@@ -11,7 +11,7 @@
 // block, LEFT-looking (S_ik - sum_m L[i][m] L[k][m]^T, then the product with W_k = L_kk^-1), dealt to the other workgroups
 // of the launch in column order.  Blocks travel through global memory: write-through (sc1) stores, one flag word per block,
 // sc1 loads on the consuming side (MI355X_MICROARCH.md, inter-workgroup visibility; every workgroup of this launch owns its
-// CU: 105 KB of LDS).
+// CU: 113 KB of LDS).
 //
 // Who computes what (the chain keeps the two sub-diagonals to itself):
 //   chain, step j:   elimination waves (0-3): [D_j; I] -> X_j -> xinv(j, j), W_j = X_j^T -> ldiag[j]; then
@@ -32,7 +32,7 @@
 
 namespace sfm {
 
-constexpr int kFlowMaxNbk = 16;      // one poll covers a row of up to 16 flags (73 cameras)
+constexpr int kFlowMaxNbk = kInvRowsMaxNbk;      // wherever the identity rows are carried (dp = X y by ba_inv_apply)
 constexpr int kFlowHdr = 16;         // header words of BaDev::flow: [0] epoch of the last finished solve, [1] workgroups done, [2] abort
 constexpr unsigned kFlowSpinLimit = 4000000u;   // polls (~0.5-1 us each) before a wait gives up and the solve reports SFM_E_HIP
 __host__ __device__ inline int flow_fl(int nbk, int i, int k) { return kFlowHdr + i * nbk + k; }                      // L[i][k] published
@@ -54,8 +54,9 @@ constexpr int FS_W = 4160;                // [2][1024] W_j, W_j-1 (k-interleaved
 constexpr int FS_LA = 6208;               // [2][1024] L[j+1][j] of this and the previous step
 constexpr int FS_LB = 8256;               // [2][1024] L[r][r-2] of this and the previous step
 constexpr int FS_B = 10304;               // [3][1024] the row being taken over: (r, r-2), (r, r-1), (r, r); tasks: T and L
-constexpr int FS_INT = 13376;             // ints: [0] elimination flag, [1] preparation-group barrier counter
-constexpr int FS_TOTAL = 13384;
+constexpr int FS_XL = 13376;              // [1024] X_j in the operand layout, for the preparation waves to publish
+constexpr int FS_INT = 14400;             // ints: elimination flag, the two group-barrier counters, the two step counters between the groups
+constexpr int FS_TOTAL = 14408;
 constexpr size_t kFlowLdsBytes = FS_TOTAL * sizeof(double);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -139,6 +140,17 @@ struct FlowWait {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the compiler from hoisting loads above the poll
   }
+  // one poll of up to three flags: all there?
+  __device__ __forceinline__ bool poll(int i0, int i1, int i2) {
+    if (dead) return true;
+    const int lane = threadIdx.x & 63;
+    const int mine = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : -1;
+    unsigned v = epoch;
+    if (mine >= 0) v = __hip_atomic_load(flow + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool all = __ballot(v != epoch) == 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return all;
+  }
   // Terms m0 .. m0+n-1 of a row sum; term t is ready when flag idx[q] + t carries the epoch for every one of the nrows <= 3 flag
   // rows (row q polled by lanes 16 q .. 16 q + 15).  Waits until `need` leading terms are ready, returns how many are.
   __device__ __forceinline__ int wait_terms(int idxa, int idxb, int idxc, int nrows, int n, int need) {
@@ -184,6 +196,7 @@ struct FlowCtx {
   double* sm; int* smi;
   int lane, lr, lk, gw, sx, sy;
   FlowWait w;
+  unsigned long long* stamps;      // SFM_OPT_DEBUG bit 8 (thread 0 of a task workgroup), else null
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -206,8 +219,10 @@ template <int OWN>
 __device__ __forceinline__ void flow_row_sum(FlowCtx& c, f64x4& acc, int arow, int own, int m0, int m1) {
   int ready = m0;
   for (int m = m0; m < m1;) {
-    if (m >= ready)
-      ready = m0 + c.w.wait_terms(flow_fl(c.nbk, arow, m0), flow_own_flag<OWN>(c, own, m0), 0, (OWN == 0 && arow == own) ? 1 : 2, m1 - m0, m - m0 + 1);
+    if (m >= ready) {
+      const int ws = m0 + ((m - m0) & ~15);      // one poll covers a window of 16 terms
+      ready = ws + c.w.wait_terms(flow_fl(c.nbk, arow, ws), flow_own_flag<OWN>(c, own, ws), 0, (OWN == 0 && arow == own) ? 1 : 2, min(16, m1 - ws), m - ws + 1);
+    }
     const int n = min(ready - m, 4);
     double a[4][8], b[4][8];
 #pragma unroll
@@ -272,9 +287,14 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   const f64x4 s0 = ctile_ld_S(c.redp + red_blk_base(i, i - 2), c.sx, c.sy, c.lr, c.lk);
   const f64x4 s2 = ctile_ld_S(c.redp + red_blk_base(i, i), c.sx, c.sy, c.lr, c.lk);
   f64x4 accT = {0, 0, 0, 0}, acc0 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  unsigned long long* stamp = c.stamps ? c.stamps + 640 + 8 * i : nullptr;
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
   int ready = 0;
   for (int m = 0; m < k;) {
-    if (m >= ready) ready = c.w.wait_terms(flow_fl(nbk, k, 0), flow_fl(nbk, i - 2, 0), flow_fl(nbk, i, 0), 3, k, m + 1);
+    if (m >= ready) {
+      const int ws = m & ~15;
+      ready = ws + c.w.wait_terms(flow_fl(nbk, k, ws), flow_fl(nbk, i - 2, ws), flow_fl(nbk, i, ws), 3, min(16, k - ws), m - ws + 1);
+    }
     const int n = min(ready - m, 2);
     double b[2][8], at[2][8], a0[2][8], a2[2][8];
 #pragma unroll
@@ -294,7 +314,9 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   double* Lx = c.sm + FS_B + kBlk;
   ctile_st_lds(Tx, coff, sT - accT);
   __syncthreads();
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
   c.w.wait(flow_fw(nbk, k), flow_fl(nbk, i - 2, k));
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
   double a[8], b[8], a0[8];
   op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
   op_sc1(c.red, red_blk_base(i - 2, k), c.sx, c.lr, c.lk, a0);
@@ -304,6 +326,7 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   ctile_st_sc1(c.red, red_blk_base(i, k), coff, o);
   ctile_st_lds(Lx, coff, o);
   __syncthreads();
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
   op_lds(Lx, c.sy, c.lr, c.lk, b);
   op_lds(Lx, c.sx, c.lr, c.lk, a);
   mfma8(acc0, a0, b);
@@ -317,6 +340,7 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
     flow_publish(c.flow, flow_fh(nbk, i, 0), c.epoch);
     flow_publish(c.flow, flow_fh(nbk, i, 2), c.epoch);
   }
+  if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
 }
 
 __device__ __forceinline__ void flow_task_rhs(FlowCtx& c, int k) {
@@ -337,8 +361,20 @@ __device__ __forceinline__ void flow_task_ident(FlowCtx& c, int e, int k) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The chain.  512 threads: waves 0-3 eliminate, waves 4-7 prepare the next row meanwhile.
+// The chain.  512 threads.  Waves 0-3 (raised priority) eliminate and never touch global memory: elimination -> X_j rows in LDS ->
+// [all waves: X_j, W_j = X_j^T into operand layout, LDS] -> L[j+1][j] -> D_j+1 -> next elimination, with barriers of their own
+// group in between.  Waves 4-7 do everything that waits for memory: they publish what the elimination waves leave in LDS (X_j,
+// W_j, L[j+1][j]: copy, drain, flag) and prepare the next row.  The two groups meet at two workgroup barriers per step (X_j rows
+// complete / operand blocks complete) and hand each other the LDS buffers through two step counters.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flow_lds_wait(const int* word, int value) {
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void flow_lds_post(int* word, int value) {      // after a group barrier: the group's LDS writes are complete
+  if ((threadIdx.x & 255) == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double lambda) {
   const int nbk = c.nbk, P = d.P;
   const int tid = threadIdx.x, lane = c.lane, grp = tid >> 8;
@@ -347,9 +383,13 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
   double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_DM);
   double(*Xm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_XM);
   f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(sm + FS_XY);
-  int* eflag = c.smi;
-  int* pctr = c.smi + 1;
-  int ptarget = 0;
+  double* Xl = sm + FS_XL;
+  int* eflag = c.smi;            // chol_trsm_cols: pair-steps published
+  int* pctr = c.smi + 1;         // barrier counter of the preparation waves
+  int* ectr = c.smi + 2;         // barrier counter of the elimination waves
+  int* la_ready = c.smi + 3;     // steps whose L[j+1][j] sits in LDS
+  int* c2_done = c.smi + 4;      // steps whose D_j+1 is formed (the row buffers B0..B2 are free again)
+  int ptarget = 0, etarget = 0;
   const int coff = ctile_off(sx, sy, lr, lk);
   unsigned long long* stamp = (d.stamps && (tid == 0 || tid == 256)) ? d.stamps + (tid == 0 ? 0 : 512) : nullptr;
 
@@ -364,8 +404,22 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
       Dm[a][kap] = t;
     }
   };
-  if (grp == 0) put_d(0, ctile_ld_S(c.redp + red_blk_base(0, 0), sx, sy, lr, lk));
-  if (tid == 0) { eflag[0] = 0; pctr[0] = 0; }
+  // a k-interleaved block from LDS to global memory by the 256 preparation threads
+  auto push_block = [&](const double* src, FlowBuf dst, size_t base) {
+    const int u0 = tid - 256;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { const int u = 2 * (u0 + 256 * h); st2_sc1(dst, base + u, *reinterpret_cast<const f64x2*>(src + u)); }
+  };
+  // preparation waves: the next row's hand-over blocks (and the operand tiles of L[r][r-3]) fetched one step ahead
+  f64x2 pf[3][2];
+  double pfb[8];
+  bool pf_ok = false;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { pf[t][0] = f64x2{0, 0}; pf[t][1] = f64x2{0, 0}; }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) pfb[t] = 0;
+  if (grp == 0) { __builtin_amdgcn_s_setprio(3); put_d(0, ctile_ld_S(c.redp + red_blk_base(0, 0), sx, sy, lr, lk)); }
+  if (tid == 0) { eflag[0] = 0; pctr[0] = 0; ectr[0] = 0; la_ready[0] = 0; c2_done[0] = 0; }
   __syncthreads();
 
   for (int j = 0; j < nbk; ++j) {
@@ -388,42 +442,44 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
       chol_trsm_cols(cc, xy, eflag, lane, gw);
       if (lane >= NB) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = 8 * gw + u; cc[u] = (k >= row) ? cc[u] : 0.0; Xm[row][k] = cc[u]; }
-        // X_j = the identity row's first block X[j][j], in the operand layout (what ba_inv_apply and the tasks of identity row j read)
-        const size_t out = red_blk_base(j, j) + gw * 256 + row * 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) st2_sc1(c.xinv, out + q * 64, f64x2{cc[q], cc[q + 4]});
+        for (int u = 0; u < 8; ++u) { const int k = 8 * gw + u; Xm[row][k] = (k >= row) ? cc[u] : 0.0; }
       }
-      flow_drain();
     } else if (has_r) {
-      // ---- preparation of row r = j + 1 beside the elimination
-      double a[8], b[8];
-      if (r >= 3) {
+      // ---- preparation of row r = j + 1 beside the elimination: wave 4 + s owns tile s of every product.  (Its 64-cycle matrix
+      // instructions share the SIMDs with the elimination waves and cost the elimination ~2 000 cycles per step; keeping a wave
+      // from issuing them while the elimination wave of its SIMD owns the pivot chain, or giving the work to the two waves whose
+      // SIMDs are idle after the first chain segments, only made the preparation the longer path: EXPERIMENTS.md.)
+      const int u0 = tid - 256;
+      if (r >= 3 && !pf_ok) {
         c.w.wait(flow_fh(nbk, r, 0), flow_fh(nbk, r, 1), flow_fh(nbk, r, 2));
-        if (stamp) stamp[8 * j + 5] = __builtin_amdgcn_s_memtime();
-        const int u0 = tid - 256;
-        f64x2 v[3][2];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) v[t][h] = ld2_sc1(c.red, red_blk_base(r, r - 2 + t) + 2 * (u0 + 256 * h));
-        op_sc1(c.red, red_blk_base(r, r - 3), sy, lr, lk, b);      // L[r][r-3]: published before the hand-over blocks
+          for (int h = 0; h < 2; ++h) pf[t][h] = ld2_sc1(c.red, red_blk_base(r, r - 2 + t) + 2 * (u0 + 256 * h));
+        op_sc1(c.red, red_blk_base(r, r - 3), sy, lr, lk, pfb);
+      }
+      if (stamp) stamp[8 * j + 5] = __builtin_amdgcn_s_memtime();
+      flow_lds_wait(c2_done, j);            // step j-1 has read the last of B0..B2
+      if (r >= 3) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) *reinterpret_cast<f64x2*>(B0 + t * kBlk + 2 * (u0 + 256 * h)) = v[t][h];
+          for (int h = 0; h < 2; ++h) *reinterpret_cast<f64x2*>(B0 + t * kBlk + 2 * (u0 + 256 * h)) = pf[t][h];
       } else {
         if (r == 2) ctile_st_lds(B0, coff, ctile_ld_S(c.redp + red_blk_base(2, 0), sx, sy, lr, lk));
         ctile_st_lds(B1, coff, ctile_ld_S(c.redp + red_blk_base(r, r - 1), sx, sy, lr, lk));
         ctile_st_lds(B2, coff, ctile_ld_S(c.redp + red_blk_base(r, r), sx, sy, lr, lk));
       }
+      pf_ok = false;
+      if (stamp) stamp[256 + 8 * j + 0] = __builtin_amdgcn_s_memtime();
       flow_group_sync(pctr, ptarget);
+      if (stamp) stamp[256 + 8 * j + 1] = __builtin_amdgcn_s_memtime();
+      f64x4 acc1 = {0, 0, 0, 0};
+      double a[8], b[8];
       if (r >= 3) {
-        // (r, r-1) -= L[r][r-3] L[r-1][r-3]^T
+        // (r, r-1) -= L[r][r-3] L[r-1][r-3]^T (kept in the accumulator until the second term is there)
         op_lds(LBprev, sx, lr, lk, a);
-        f64x4 acc = {0, 0, 0, 0};
-        mfma8(acc, a, b);
-        ctile_st_lds(B1, coff, ctile_ld_lds(B1, coff) - acc);
+        mfma8(acc1, a, pfb);
       }
       if (r >= 2) {
         // L[r][r-2]^T = W_j-1 T^T
@@ -433,44 +489,46 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
         mfma8(o, a, b);
         ctile_st_lds(LBcur, coff, o);
         ctile_st_sc1(c.red, red_blk_base(r, r - 2), coff, o);
+        if (stamp) stamp[256 + 8 * j + 3] = __builtin_amdgcn_s_memtime();
         flow_group_sync(pctr, ptarget);
-        // (r, r-1) -= L[r][r-2] L[r-1][r-2]^T ; (r, r) -= L[r][r-2] L[r][r-2]^T
+        if (stamp) stamp[256 + 8 * j + 4] = __builtin_amdgcn_s_memtime();
+        // (r, r-1) -= L[r][r-2] L[r-1][r-2]^T ; (r, r) -= L[r][r-2] L[r][r-2]^T (lower tiles)
         op_lds(LBcur, sy, lr, lk, b);
         op_lds(LAprev, sx, lr, lk, a);
-        f64x4 acc = {0, 0, 0, 0};
-        mfma8(acc, a, b);
-        ctile_st_lds(B1, coff, ctile_ld_lds(B1, coff) - acc);
+        mfma8(acc1, a, b);
+        ctile_st_lds(B1, coff, ctile_ld_lds(B1, coff) - acc1);
         if (gw != 2) {
           op_lds(LBcur, sx, lr, lk, a);
           f64x4 acc2 = {0, 0, 0, 0};
-          mfma8(acc2, a, b);
+            mfma8(acc2, a, b);
           ctile_st_lds(B2, coff, ctile_ld_lds(B2, coff) - acc2);
         }
       }
-      flow_drain();
       if (stamp) stamp[8 * j + 6] = __builtin_amdgcn_s_memtime();
+      // the next row's hand-over, if it is there already: its loads travel while the elimination finishes
+      if (r + 1 < nbk && r + 1 >= 3 && c.w.poll(flow_fh(nbk, r + 1, 0), flow_fh(nbk, r + 1, 1), flow_fh(nbk, r + 1, 2))) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) pf[t][h] = ld2_sc1(c.red, red_blk_base(r + 1, r - 1 + t) + 2 * (u0 + 256 * h));
+        op_sc1(c.red, red_blk_base(r + 1, r - 2), sy, lr, lk, pfb);
+        pf_ok = true;
+      }
     }
-    __syncthreads();                                                  // B: X_j in Xm, row r prepared
+    __syncthreads();                                                  // B: X_j rows in Xm, row r prepared
     if (stamp) stamp[8 * j + 1] = __builtin_amdgcn_s_memtime();
     {
-      // W_j = X_j^T into the operand layout: LDS (this step's TRSM, the next step's preparation) and ldiag[j] (the tasks)
-      const int m = tid >> 7, lk2 = (tid >> 5) & 3, col = tid & 31, kap = 8 * m + lk2;
-      const f64x2 v = {Xm[kap][col], Xm[kap + 4][col]};
-      const int off = m * 256 + lk2 * 64 + 2 * col;
-      *reinterpret_cast<f64x2*>(Wcur + off) = v;
-      st2_sc1(c.ldiag, (size_t)j * kBlk + off, v);
-      flow_drain();
+      // X_j and W_j = X_j^T into the operand layout (LDS): W_j for this step's TRSM and the next step's preparation, both for the
+      // preparation waves to publish (ldiag[j]: the tasks; xinv(j, j): ba_inv_apply and the tasks of identity row j)
+      const int m = tid >> 7, q = (tid >> 5) & 3, col = tid & 31, kap = 8 * m + q;
+      const int off = m * 256 + q * 64 + 2 * col;
+      *reinterpret_cast<f64x2*>(Wcur + off) = f64x2{Xm[kap][col], Xm[kap + 4][col]};
+      *reinterpret_cast<f64x2*>(Xl + off) = f64x2{Xm[col][kap], Xm[col][kap + 4]};
     }
-    __syncthreads();                                                  // C
-    if (tid == 0) {
-      flow_publish(c.flow, flow_fw(nbk, j), c.epoch);
-      flow_publish(c.flow, flow_fx(nbk, j, j), c.epoch);
-      if (has_r && r >= 2) flow_publish(c.flow, flow_fl(nbk, r, r - 2), c.epoch);
-      eflag[0] = 0;
-    }
+    __syncthreads();                                                  // C: operand blocks complete
     if (stamp) stamp[8 * j + 2] = __builtin_amdgcn_s_memtime();
-    if (!has_r) break;
     if (grp == 0) {
+      if (!has_r) break;
       // L[r][j]^T = W_j T^T
       double a[8], b[8];
       op_lds(Wcur, sx, lr, lk, a);
@@ -478,23 +536,40 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
       f64x4 o = {0, 0, 0, 0};
       mfma8(o, a, b);
       ctile_st_lds(LAcur, coff, o);
-      ctile_st_sc1(c.red, red_blk_base(r, j), coff, o);
+      if (tid == 0) eflag[0] = 0;
+      flow_group_sync(ectr, etarget);
+      flow_lds_post(la_ready, j + 1);
+      if (stamp) stamp[8 * j + 3] = __builtin_amdgcn_s_memtime();
+      if (gw != 2) {
+        // D_r -= L[r][j] L[r][j]^T, lower tiles only
+        op_lds(LAcur, sx, lr, lk, a);
+        op_lds(LAcur, sy, lr, lk, b);
+        f64x4 acc = {0, 0, 0, 0};
+        mfma8(acc, a, b);
+        put_d(r, ctile_ld_lds(B2, coff) - acc);
+      }
+      flow_group_sync(ectr, etarget);
+      flow_lds_post(c2_done, j + 1);
+      if (stamp) stamp[8 * j + 4] = __builtin_amdgcn_s_memtime();
+    } else {
+      // publish X_j, W_j, then L[r][j] as soon as the elimination waves have it
+      push_block(Xl, c.xinv, red_blk_base(j, j));
+      push_block(Wcur, c.ldiag, (size_t)j * kBlk);
       flow_drain();
+      flow_group_sync(pctr, ptarget);
+      if (tid == 256) {
+        flow_publish(c.flow, flow_fw(nbk, j), c.epoch);
+        flow_publish(c.flow, flow_fx(nbk, j, j), c.epoch);
+        if (has_r && r >= 2) flow_publish(c.flow, flow_fl(nbk, r, r - 2), c.epoch);      // stored by the preparation above, drained here
+      }
+      if (!has_r) break;
+      flow_lds_wait(la_ready, j + 1);
+      push_block(LAcur, c.red, red_blk_base(r, j));
+      flow_drain();
+      flow_group_sync(pctr, ptarget);
+      if (tid == 256) flow_publish(c.flow, flow_fl(nbk, r, j), c.epoch);
+      if (stamp) stamp[8 * j + 7] = __builtin_amdgcn_s_memtime();
     }
-    __syncthreads();                                                  // D
-    if (tid == 0) flow_publish(c.flow, flow_fl(nbk, r, j), c.epoch);
-    if (stamp) stamp[8 * j + 3] = __builtin_amdgcn_s_memtime();
-    if (grp == 0 && gw != 2) {
-      // D_r -= L[r][j] L[r][j]^T, lower tiles only
-      double a[8], b[8];
-      op_lds(LAcur, sx, lr, lk, a);
-      op_lds(LAcur, sy, lr, lk, b);
-      f64x4 acc = {0, 0, 0, 0};
-      mfma8(acc, a, b);
-      put_d(r, ctile_ld_lds(B2, coff) - acc);
-    }
-    __syncthreads();                                                  // A
-    if (stamp) stamp[8 * j + 4] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -513,6 +588,7 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   c.lane = tid & 63; c.lr = c.lane & 15; c.lk = c.lane >> 4;
   c.gw = (tid >> 6) & 3; c.sx = c.gw >> 1; c.sy = c.gw & 1;
   c.w = FlowWait{flow, c.epoch, d.status, false};
+  c.stamps = (d.stamps && tid == 0) ? d.stamps : nullptr;
   if (blockIdx.x == 0) {
     flow_chain(c, d, lambda);
   } else {

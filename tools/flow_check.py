@@ -23,14 +23,22 @@ if len(sys.argv) > 1 and sys.argv[1] == "stamps":
     el, pr = raw[:128].reshape(16, 8), raw[512:640].reshape(16, 8)
     t0 = el[0, 0]
     for j in range(11):
-        print("step %2d  start %6d  elim+prep %5d  transpose %4d  trsm %4d  syrk %4d | prep: hand-over seen %6d, done %6d (rel. to step start)" % (
-            j, el[j, 0] - t0, el[j, 1] - el[j, 0], el[j, 2] - el[j, 1], el[j, 3] - el[j, 2], el[j, 4] - el[j, 3], pr[j, 5] - el[j, 0], pr[j, 6] - el[j, 0]))
+        print("step %2d  start %6d  elim+prep %5d  transpose %4d  trsm %4d  syrk %4d | prep: hand-over seen %6d, done %6d, L published %6d (rel. to step start)" % (
+            j, el[j, 0] - t0, el[j, 1] - el[j, 0], el[j, 2] - el[j, 1], el[j, 3] - el[j, 2], el[j, 4] - el[j, 3], pr[j, 5] - el[j, 0], pr[j, 6] - el[j, 0], pr[j, 7] - el[j, 0]))
+    pd = raw[768:896].reshape(16, 8)
+    for j in range(10):
+        print("prep %2d (rel. to step start): seen %6d  regs->LDS %6d  sync %6d  d'+trsm %6d  sync %6d  done %6d" % (
+            j, pr[j, 5] - el[j, 0], pd[j, 0] - el[j, 0], pd[j, 1] - el[j, 0], pd[j, 3] - el[j, 0], pd[j, 4] - el[j, 0], pr[j, 6] - el[j, 0]))
     print("chain total ticks", el[10, 2] - t0)
+    cl = raw[640:768].reshape(16, 8)
+    for i in range(3, 11):
+        print("closer %2d (needs W_%d, hand-over wanted at step %d start = %6d): start %6d  sums done %6d  W seen %6d  L formed %6d  published %6d   [chain: W_%d ready %6d]" % (
+            i, i - 3, i - 1, el[i - 1, 0] - t0, cl[i, 0] - t0, cl[i, 1] - t0, cl[i, 2] - t0, cl[i, 3] - t0, cl[i, 4] - t0, i - 3, el[i - 3, 2] - t0))
     sys.exit(0)
 
 oracle = importlib.import_module("sfm_oracle")
 worst = 0.0
-for (V, N, vis, seed) in ((9, 300, 0.8, 1), (10, 400, 0.6, 2), (14, 500, 0.5, 3), (19, 600, 0.5, 4), (28, 600, 0.4, 5), (37, 700, 0.4, 6), (50, 900, 0.6, 7), (64, 900, 0.3, 8), (73, 900, 0.3, 9)):
+for (V, N, vis, seed) in ((9, 300, 0.8, 1), (10, 400, 0.6, 2), (14, 500, 0.5, 3), (19, 600, 0.5, 4), (28, 600, 0.4, 5), (37, 700, 0.4, 6), (50, 900, 0.6, 7), (64, 900, 0.3, 8), (73, 900, 0.3, 9), (74, 900, 0.3, 10), (120, 1500, 0.2, 11), (200, 2500, 0.15, 12), (237, 2500, 0.15, 13)):
     sc = sfm.scenes.make_scene(V, N, vis, seed=seed); uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     t0 = time.time()
     c_new, p_new = run(sc, uvn, 0, 2)

@@ -1,0 +1,8 @@
+#!/bin/bash
+out=gpurun_out/flow3; mkdir -p $out; export TMPDIR=/tmp
+timeout -k 10 300 python tools/flow_check.py > $out/check.txt 2>&1; echo "check rc=$?" | tee $out/steps.log; grep -v amdgpu $out/check.txt | tail -8
+[ "$(tail -1 $out/steps.log)" = "check rc=0" ] || exit 1
+timeout -k 10 300 python tools/time_solve_paths.py > $out/time_solve_paths.txt 2>&1; echo "paths rc=$?" | tee -a $out/steps.log; grep -v amdgpu $out/time_solve_paths.txt
+for dbg in 0 1024; do
+timeout -k 10 200 python bench.py --config C4 --pts 12500 --steps 20 --warmup 3 --no-cpu-baseline --repeats 3 --debug $dbg 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C4share debug $dbg', round(d['value'],1), round(d['ms_per_step']*1e3,2), {k: round(v*1e3,1) for k,v in d['kernel_ms'].items()})" | tee -a $out/bench.txt
+done
