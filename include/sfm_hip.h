@@ -67,7 +67,7 @@ extern "C" {
                               * contribution (many cameras at low visibility: BASELINE config 4) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product: results unchanged) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 1024 = the column steps of the reduced solve as separate launches (ba_chol_step) where the single data-flow launch would run (9 to 237 cameras): results unchanged) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
@@ -335,6 +335,11 @@ int sfm_ba_reset_timing(sfm_ba_problem* p);
 int sfm_ba_event_overhead(sfm_ba_problem* p, int n, double* avg_ms);
 /* Diagnostic: shader-clock stamps written by instrumented kernels when SFM_OPT_DEBUG has bit 8 set. */
 int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n);
+/* Diagnostic (host only, needs no device): the task table of the data-flow reduced solve for nbk = ceil(7 V / 32) block columns,
+ * in the order its workgroups take it: {type, row, column, sort key} per task, type 0 = a block of L, 1 = the last library-side
+ * block of a row + its two hand-over blocks, 2 = the hand-over block (i, i-1), 3 = a block of the rhs row, 4 = a block of an
+ * identity row.  Returns the number of tasks (0 outside 2 .. 52 block columns); fills at most `capacity` of them. */
+int sfm_ba_flow_tasks(int nbk, int* out, int capacity);
 
 /* Multi-GPU split of one iteration (points sharded by rank, cameras replicated):
  *   sfm_ba_linearize_reduce : this rank's partial reduced system [S (P x P, P = 7V padded to

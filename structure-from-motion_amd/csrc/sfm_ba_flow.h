@@ -56,7 +56,7 @@ constexpr int FS_LB = 8256;               // [2][1024] L[r][r-2] of this and the
 constexpr int FS_B = 10304;               // [3][1024] the row being taken over: (r, r-2), (r, r-1), (r, r); tasks: T and L
 constexpr int FS_XL = 13376;              // [1024] X_j in the operand layout, for the preparation waves to publish
 constexpr int FS_INT = 14400;             // ints: elimination flag, the two group-barrier counters, the two step counters between the groups
-constexpr int FS_TOTAL = 14408;
+constexpr int FS_TOTAL = 14416;
 constexpr size_t kFlowLdsBytes = FS_TOTAL * sizeof(double);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -315,10 +315,12 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   ctile_st_lds(Tx, coff, sT - accT);
   __syncthreads();
   if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
-  c.w.wait(flow_fw(nbk, k), flow_fl(nbk, i - 2, k));
-  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+  // W_k is published ~1 300 cycles before L[i-2][k]: its load travels while the second flag is polled
   double a[8], b[8], a0[8];
+  c.w.wait(flow_fw(nbk, k));
   op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
+  c.w.wait(flow_fl(nbk, i - 2, k));
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
   op_sc1(c.red, red_blk_base(i - 2, k), c.sx, c.lr, c.lk, a0);
   op_lds(Tx, c.sy, c.lr, c.lk, b);
   f64x4 o = {0, 0, 0, 0};
@@ -358,6 +360,72 @@ __device__ __forceinline__ void flow_task_ident(FlowCtx& c, int e, int k) {
   f64x4 acc = {0, 0, 0, 0};
   flow_row_sum<2>(c, acc, k, e, e, k);
   flow_finish<2>(c, -acc, e, k);
+}
+
+// dp_e = sum_{c >= e} X[e][c] y_c for identity row e (what ba_inv_apply does in its own launch), run by the workgroup that
+// has just published the last block of the row (e < nbk-1) or the last block of y (e = nbk-1); the workgroup whose part
+// arrives last updates the cameras (ba:383-392) and prepares the next iteration's.  Thread (row i, slice): every 8th block.
+__device__ __forceinline__ void flow_task_dp(FlowCtx& c, const BaDev& d, int e, int cur) {
+  const int nbk = c.nbk, tid = threadIdx.x, i = tid & 31, slice = tid >> 5, n = nbk - e;
+  double* ys = c.sm + FS_B;                   // y_e .. y_nbk-1
+  double* part = c.sm + FS_B + 2 * kBlk;      // [8][33]
+  for (int w0 = 0; w0 < n; w0 += 16)          // every block of the row and of y is there
+    (void)c.w.wait_terms(flow_fx(nbk, e, e + w0), flow_fy(nbk, e + w0), 0, 2, min(16, n - w0), min(16, n - w0));
+  for (int t = tid; t < n * kNB; t += 256) ys[t] = __hip_atomic_load(c.rhs + e * kNB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f64x2 w[2][16];
+  double s = 0;
+  __syncthreads();
+  for (int cc = e + slice; cc < nbk; cc += 16) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (cc + 8 * h < nbk) {
+        const size_t blk = red_blk_base(cc + 8 * h, e) + 2 * i;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[h][4 * m + q] = ld2_sc1(c.xinv, blk + m * 256 + q * 64);      // columns 8m+q, 8m+q+4 of row i
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (cc + 8 * h < nbk) {
+        const double* yc = ys + (cc + 8 * h - e) * kNB;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s = __builtin_fma(w[h][4 * m + q].y, yc[8 * m + q + 4], __builtin_fma(w[h][4 * m + q].x, yc[8 * m + q], s));
+      }
+  }
+  part[slice * 33 + i] = s;
+  __syncthreads();
+  if (tid < kNB) {
+    double t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += part[q * 33 + tid];
+    __hip_atomic_store(d.delta + e * kNB + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  flow_drain();
+  __syncthreads();
+  int* is_last = c.smi + 15;
+  if (tid == 0) {
+    const int done = __hip_atomic_fetch_add(d.sync_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *is_last = done == nbk - 1;
+    if (done == nbk - 1) __hip_atomic_store(d.sync_ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next solve
+  }
+  __syncthreads();
+  if (!*is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
+  for (int v = tid; v < d.V; v += 256) {
+    double cam[7];
+    for (int k = 0; k < 7; ++k) cam[k] = d.cams[7 * v + k] + __hip_atomic_load(d.delta + 7 * v + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ba:383
+    const double nq = sqrt(cam[3] * cam[3] + cam[4] * cam[4] + cam[5] * cam[5] + cam[6] * cam[6]);   // ba:388-392
+    for (int k = 3; k < 7; ++k) cam[k] /= nq;
+    for (int k = 0; k < 7; ++k) d.cams[7 * v + k] = cam[k];
+    CamPrep out;
+    const int st = cam_prepare(cam, &out);      // ba:323 of the next iteration / ba:412 after the last one
+    d.prep[cur ^ 1][v] = out;
+    report_status(d.status, st, v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -575,7 +643,7 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
 
 // Workgroup 0 is the chain; workgroup b >= 1 takes tasks b-1, b-1 + (grid-1), ... of the table (sorted by column: a task waits
 // only for tasks of earlier columns, so every workgroup's list can be run in order once all workgroups are resident).
-__global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda) {
+__global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda, int cur) {
   extern __shared__ __attribute__((aligned(16))) double flow_sm[];
   const int tid = threadIdx.x;
   if (blockIdx.x != 0 && tid >= 256) return;      // tasks are run by four waves
@@ -598,8 +666,14 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
         case FLOW_T1: flow_task_t1(c, tk.i, tk.k); break;
         case FLOW_CLOSER: flow_task_closer(c, tk.i); break;
         case FLOW_H1: flow_task_h1(c, tk.i); break;
-        case FLOW_RHS: flow_task_rhs(c, tk.k); break;
-        default: flow_task_ident(c, tk.i, tk.k); break;
+        case FLOW_RHS:
+          flow_task_rhs(c, tk.k);
+          if (cur >= 0 && tk.k == d.nbk - 1) flow_task_dp(c, d, d.nbk - 1, cur);
+          break;
+        default:
+          flow_task_ident(c, tk.i, tk.k);
+          if (cur >= 0 && tk.k == d.nbk - 1) flow_task_dp(c, d, tk.i, cur);
+          break;
       }
     }
   }
@@ -620,8 +694,8 @@ inline std::vector<FlowTask> flow_build_tasks(int nbk) {
   std::vector<FlowTask> t;
   for (int i = 3; i < nbk; ++i) {
     t.push_back(FlowTask{FLOW_CLOSER, i, i - 3, 8 * (i - 3) + 0});
-    t.push_back(FlowTask{FLOW_H1, i, i - 1, 8 * std::max(0, i - 4) + 1});
-    for (int k = 0; k <= i - 4; ++k) t.push_back(FlowTask{FLOW_T1, i, k, 8 * k + 2});
+    t.push_back(FlowTask{FLOW_H1, i, i - 1, 8 * std::max(0, i - 4) + 2});      // after the block (i, i-4) of the same column
+    for (int k = 0; k <= i - 4; ++k) t.push_back(FlowTask{FLOW_T1, i, k, 8 * k + 1});
   }
   for (int k = 0; k < nbk; ++k) t.push_back(FlowTask{FLOW_RHS, 0, k, 8 * k + 3});
   for (int e = 0; e + 1 < nbk; ++e)

@@ -793,8 +793,10 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   // SFM_OPT_DEBUG bit 1024: column steps as separate launches where the data-flow launch would run
   if (with_inv && d.flow != nullptr && !(d.debug & 1024)) {
     const int grid = 1 + std::min(d.flow_ntasks, ctx().num_cus - 32);
-    ba_chol_flow_kernel<<<grid, 512, kFlowLdsBytes, s>>>(d, d.flow, static_cast<const FlowTask*>(d.flow_tasks), d.flow_ntasks, lambda);
-    ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
+    // SFM_OPT_DEBUG bit 2048: dp = X y and the camera update as their own launch behind the data-flow launch
+    const bool fused_dp = !(d.debug & 2048);
+    ba_chol_flow_kernel<<<grid, 512, kFlowLdsBytes, s>>>(d, d.flow, static_cast<const FlowTask*>(d.flow_tasks), d.flow_ntasks, lambda, fused_dp ? p->cur : -1);
+    if (!fused_dp) ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
     SFM_HIP(hipGetLastError());
     return SFM_OK;
   }
@@ -835,6 +837,20 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
+
+}  // namespace sfm
+
+// Diagnostic (CPU only, no device needed): the task table of the data-flow solve for nbk block columns, in the order the
+// workgroups take it -- int[4] per task: {type (0 block of L, 1 closer, 2 hand-over (i, i-1), 3 rhs, 4 identity row), row, column, key}.
+extern "C" int sfm_ba_flow_tasks(int nbk, int* out, int capacity) {
+  if (nbk < 2 || nbk > sfm::kFlowMaxNbk) return 0;
+  const std::vector<sfm::FlowTask> t = sfm::flow_build_tasks(nbk);
+  if (out != nullptr)
+    for (size_t q = 0; q < t.size() && (int)q < capacity; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].k; out[4 * q + 3] = t[q].key; }
+  return (int)t.size();
+}
+
+namespace sfm {
 
 void ba_enqueue_symmetrize(sfm_ba_problem* p, double lambda, double* S_out, double* rhs_out) {
   const BaDev& d = p->dev;

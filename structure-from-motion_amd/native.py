@@ -40,7 +40,7 @@ EXPORTS = (
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
     "sfm_pool_mode", "sfm_tri_nonlinear_dev", "sfm_tri_linear_dev", "sfm_triangulate_dev", "sfm_pnp_nonlinear_batch_dev",
     "sfm_gather_points_dev", "sfm_ba_points_ptr", "sfm_ba_stream", "sfm_ba_event_overhead",
-    "sfm_ba_get_state_rot", "sfm_ba_rederive_quaternions",
+    "sfm_ba_get_state_rot", "sfm_ba_rederive_quaternions", "sfm_ba_flow_tasks",
 )
 
 _lib = None
@@ -183,6 +183,18 @@ def set_stream(stream_ptr):
 
 def synchronize():
     check(load().sfm_synchronize())
+
+
+def flow_tasks(nbk):
+    """Task table of the data-flow reduced solve for nbk block columns (host only; no device call): (n, 4) int32 rows
+    {type, row, column, sort key} in the order the workgroups take them."""
+    lib = load()
+    lib.sfm_ba_flow_tasks.argtypes = [ctypes.c_int, _ip, ctypes.c_int]
+    n = lib.sfm_ba_flow_tasks(int(nbk), None, 0)
+    out = np.zeros((max(n, 1), 4), dtype=np.int32)
+    if n > 0:
+        lib.sfm_ba_flow_tasks(int(nbk), iptr(out), n)
+    return out[:n]
 
 
 def pool_redzone_active():

@@ -345,3 +345,48 @@ def test_q13_sign_oracle_and_winner_rule_against_the_reference_chain(sfm, golden
     assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 0, 9]), lambda k: False) == (1, False)
     assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 0, 9]), lambda k: k == 3) == (3, True)
     assert q13.reference_winner(np.array([3, 7, 7, 2]), np.array([0, 0, 7, 9]), lambda k: k == 1) == (2, False)
+
+
+@pytest.mark.parametrize("nbk", [2, 3, 4, 5, 11, 16, 17, 44, 52])
+def test_flow_task_table_is_complete_and_dependency_ordered(sfm, nbk):
+    """The data-flow reduced solve (csrc/sfm_ba_flow.h) deals its tasks to the workgroups in table order and is deadlock-free only
+    if every task comes after the tasks it waits for.  Restated here from the kernel's waits: a block of L / the rhs row / an
+    identity row in column k needs the blocks of its own row and of row k left of k; the closer of row i needs the blocks of
+    rows i-3, i-2, i through column i-4; the hand-over block (i, i-1) rows i-1 and i through column i-4.  Blocks within two
+    block rows of the diagonal, W_k and X_k come from the chain workgroup, which waits only for hand-overs of earlier columns."""
+    tab = sfm.native.flow_tasks(nbk)
+    T1, CLOSER, H1, RHS, IDENT = 0, 1, 2, 3, 4
+    pos = {}
+    for n, (ty, i, k, key) in enumerate(tab.tolist()):
+        name = {T1: ("L", i, k), CLOSER: ("L", i, i - 3), H1: ("H1", i), RHS: ("y", k), IDENT: ("X", i, k)}[ty]
+        assert name not in pos
+        pos[name] = n
+    # completeness: every block the chain does not produce has exactly one task
+    want = {("L", i, k) for i in range(3, nbk) for k in range(0, i - 2)} | {("H1", i) for i in range(3, nbk)}
+    want |= {("y", k) for k in range(nbk)} | {("X", e, k) for e in range(nbk - 1) for k in range(e + 1, nbk)}
+    assert set(pos) == want
+    assert np.all(np.diff(tab[:, 3]) >= 0)
+
+    def before(dep, n):          # dep produced by the chain, or by an earlier task
+        assert dep not in pos or pos[dep] < n, (dep, n)
+
+    for n, (ty, i, k, key) in enumerate(tab.tolist()):
+        if ty == T1 or ty == CLOSER:
+            k = k if ty == T1 else i - 3
+            for m in range(k):
+                before(("L", i, m), n); before(("L", k, m), n)
+            if ty == CLOSER:
+                for m in range(k):
+                    before(("L", i - 2, m), n)
+        elif ty == H1:
+            for m in range(i - 3):
+                before(("L", i, m), n); before(("L", i - 1, m), n)
+        elif ty == RHS:
+            for m in range(k):
+                before(("y", m), n); before(("L", k, m), n)
+        else:
+            for m in range(i, k):
+                before(("L", k, m), n)
+                if m > i:
+                    before(("X", i, m), n)
+    assert sfm.native.flow_tasks(1).shape[0] == 0 and sfm.native.flow_tasks(53).shape[0] == 0

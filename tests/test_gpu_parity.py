@@ -403,6 +403,56 @@ def test_ba_inverse_rows_against_block_back_substitution(hip, oracle, sfm, n_cam
     assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
 
 
+@pytest.mark.parametrize("n_cams,n_pts,vis", [(9, 600, 0.8), (10, 800, 0.6), (14, 900, 0.5), (19, 900, 0.5), (50, 1500, 0.6), (73, 1200, 0.3),
+                                               (74, 1200, 0.3), (150, 2500, 0.15), (237, 2500, 0.15)])
+def test_ba_data_flow_solve_against_column_steps_and_oracle(hip, oracle, sfm, n_cams, n_pts, vis):
+    """The reduced solve as one persistent data-flow launch (csrc/sfm_ba_flow.h: 2 to 52 block columns, the default) against the
+    column steps as separate launches (SFM_OPT_DEBUG bit 1024) and both against the oracle: 2, 3, 4, 5 block columns (no task of
+    the third sub-diagonal / the first closer), 11 (C3), 16 / 17 (the 16-flag poll window), 33 and 52 (several tasks per workgroup)."""
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=500 + n_cams)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    out = []
+    for dbg in (0, 1024):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            out.append(prob.get_state())
+    for cams, pts in out:
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+    assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
+
+
+@pytest.mark.parametrize("n_cams", [12, 50, 120])
+def test_ba_data_flow_solve_is_bitwise_repeatable(hip, sfm, n_cams):
+    """Every block of the data-flow solve is produced by one task with a fixed summation order, whatever the timing of the
+    hand-overs: in deterministic mode (fixed order in the other kernels as well) ten solves of the same state agree bit for bit,
+    also while a second problem runs its own data-flow solves on another stream."""
+    import torch
+    sc = sfm.scenes.make_scene(n_cams, 1500, 0.4, seed=900 + n_cams)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    other = sfm.scenes.make_scene(40, 1200, 0.5, seed=77)
+    uvo = sfm.geometry.normalise_pixels(other.uv_pix, other.intrinsic)
+    side = torch.cuda.Stream()
+    ref = None
+    with hip.BaProblem(other.n_cams, other.pt_ptr, other.cam_idx, uvo) as noise:
+        noise.set_stream(side.cuda_stream)
+        noise.set_state(other.cams_init, other.pts_init)
+        for rep in range(10):
+            with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+                prob.set_option(hip.OPT_DETERMINISTIC, 1)
+                prob.set_state(sc.cams_init, sc.pts_init)
+                if rep % 2:
+                    noise.iterate(5.0, 4)
+                prob.iterate(5.0, 3)
+                cams, pts = prob.get_state()
+            if ref is None:
+                ref = (cams.copy(), pts.copy())
+            assert np.array_equal(cams, ref[0]) and np.array_equal(pts, ref[1])
+        noise.get_state()
+
+
 @pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
 def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
     """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;

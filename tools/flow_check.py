@@ -16,9 +16,9 @@ def run(sc, uvn, dbg, iters, lam=5.0):
 if len(sys.argv) > 1 and sys.argv[1] == "stamps":
     sc = sfm.scenes.make_config("C3", seed=0); uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
     with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
-        prob.set_option(native.OPT_DEBUG, 8)
+        prob.set_option(native.OPT_DEBUG, 8 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
         prob.set_state(sc.cams_init, sc.pts_init)
-        prob.iterate(5.0, 4); native.synchronize()
+        prob.iterate(5.0, 1); native.synchronize()
         raw = prob.debug_stamps(1024).astype(np.int64)
     el, pr = raw[:128].reshape(16, 8), raw[512:640].reshape(16, 8)
     t0 = el[0, 0]
