@@ -91,7 +91,7 @@ def algorithmic_costs(n_cams, pt_ptr, n_obs):
     }
 
 
-def steady_state_launches(n_cams, schur_kernel, fused):
+def steady_state_launches(n_cams, schur_kernel, fused, debug=0):
     """Kernels ONE steady-state iteration launches and how often (what `hbm.measured_bytes_per_iteration` may sum):
     one-time kernels (ba_structure, ba_cam_major_*, ba_cam_prep) and the stand-alone ba_backsub of a fused iteration
     are not among them."""
@@ -104,9 +104,13 @@ def steady_state_launches(n_cams, schur_kernel, fused):
         launches["ba_backsub"] = 1
     if p <= 56:
         launches["ba_small_solve"] = 1
+    elif nbk <= 52 and not (debug & (512 | 1024)):
+        launches["ba_chol_flow"] = 1            # the data-flow launch (csrc/sfm_ba_flow.h): factorisation, dp = X y, camera update
+        if debug & 2048:
+            launches["ba_inv_apply"] = 1
     else:
         launches["ba_chol_step"] = nbk
-        if nbk <= 52:
+        if nbk <= 52 and not (debug & 512):
             launches["ba_inv_apply"] = 1
         else:
             groups = (nbk + 11) // 12
@@ -524,9 +528,9 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
             traffic_rec = json.load(open(tfile)).get(workload_key)
         except Exception:
             traffic_rec = None
-    launches = steady_state_launches(scene.n_cams, schur_kernel, fused=scene.n_cams <= 102 and not (args.debug & 16))
+    launches = steady_state_launches(scene.n_cams, schur_kernel, fused=scene.n_cams <= 102 and not (args.debug & 16), debug=args.debug)
     if traffic_rec:
-        kernels = {"solve": ("ba_chol_step", "ba_inv_apply", "ba_back_solve", "ba_back_update", "ba_small_solve"), "schur": (schur_kernel,),
+        kernels = {"solve": ("ba_chol_flow", "ba_chol_step", "ba_inv_apply", "ba_back_solve", "ba_back_update", "ba_small_solve"), "schur": (schur_kernel,),
                    "reduce": ("ba_schur_reduce", "ba_schur_rows_reduce")}.get(dominant, ("ba_" + dominant,))
         per = {k: traffic_rec[k] * launches[k] for k in kernels if k in launches and isinstance(traffic_rec.get(k), (int, float))}
         if per:

@@ -10,8 +10,9 @@ done
 for f in bench bench_tri bench_pnp bench_c5 bench_c4_share bench_c4_full bench_tri_pnp probe_solve time_schur; do
   [ -f "$src/$f.log" ] && grep -E '^\{|kernel us|^\[' "$src/$f.log" | tail -20 > "$dst/$f.json"
 done
-for f in time_small stamps_small; do
+for f in time_small stamps_small flow_stamps time_solve_paths; do
   [ -f "$src/$f.log" ] && grep -v amdgpu.ids "$src/$f.log" > "$dst/$f.txt"
+  [ -f "$src/$f.txt" ] && grep -v amdgpu.ids "$src/$f.txt" > "$dst/$f.txt"
 done
 tail -3 "$src/pytest_gpu.log" > "$dst/pytest_gpu_tail.txt"
 [ -f "$src/pytest_gpu_redzone.log" ] && tail -1 "$src/pytest_gpu_redzone.log" > "$dst/pytest_gpu_redzone_tail.txt"

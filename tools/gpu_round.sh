@@ -33,6 +33,8 @@ step 240 "$out/bench_c4_share.log" python bench.py --config C4 --pts 12500 --ste
 step 240 "$out/bench_c4_full.log" python bench.py --config C4 --steps 5 --warmup 1 --no-cpu-baseline
 step 240 "$out/bench_tri_pnp.log" python tools/bench_tri_pnp.py
 step 120 "$out/probe_solve.log" python tools/probe_solve.py
+step 120 "$out/flow_stamps.txt" python tools/flow_check.py stamps
+step 300 "$out/time_solve_paths.txt" python tools/time_solve_paths.py
 step 120 "$out/time_schur.log" python tools/time_schur.py
 step 120 "$out/time_small.log" python tools/time_small.py
 step 60 "$out/stamps_small.log" python tools/stamps_small.py

@@ -10,7 +10,7 @@ native.init(0)
 sc = sfm.scenes.make_config("C3", seed=0)
 uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
 with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
-    prob.set_option(native.OPT_DEBUG, 8)
+    prob.set_option(native.OPT_DEBUG, 8 | 1024)      # the column steps as separate launches (the data-flow launch: tools/flow_check.py stamps)
     prob.set_state(sc.cams_init, sc.pts_init)
     prob.iterate(5.0, 3)
     native.synchronize()
