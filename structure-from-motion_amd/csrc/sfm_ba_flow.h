@@ -33,7 +33,9 @@
 namespace sfm {
 
 constexpr int kFlowMaxNbk = kInvRowsMaxNbk;      // wherever the identity rows are carried (dp = X y by ba_inv_apply)
-constexpr int kFlowHdr = 16;         // header words of BaDev::flow: [0] epoch of the last finished solve, [1] workgroups done, [2] abort
+constexpr int kFlowHdr = 128;        // header words of BaDev::flow, the hot ones on 128-byte lines of their own: [0] epoch of the last finished solve,
+                                     // [2] abort (read-mostly, polled rarely), [32] workgroups done, [64] tasks taken (one atomic per task); flags from [128]
+constexpr int kFlowDone = 32, kFlowTicket = 64;
 constexpr unsigned kFlowSpinLimit = 4000000u;   // polls (~0.5-1 us each) before a wait gives up and the solve reports SFM_E_HIP
 __host__ __device__ inline int flow_fl(int nbk, int i, int k) { return kFlowHdr + i * nbk + k; }                      // L[i][k] published
 __host__ __device__ inline int flow_fx(int nbk, int e, int m) { return kFlowHdr + nbk * nbk + e * nbk + m; }          // X[e][m] published
@@ -121,6 +123,12 @@ __device__ __forceinline__ f64x4 ctile_ld_S(const double* blk, int sx, int sy, i
 // every wave passes -- stays what it is, the results are garbage and d.status says so.
 struct FlowWait {
   unsigned* flow; unsigned epoch; int* status; bool dead;
+  // the abort word sits on a line every waiting wave of the launch would hammer: it is looked at every 64th poll only
+  __device__ __forceinline__ bool aborted() {
+    unsigned v = 0;
+    if ((threadIdx.x & 63) == 0) v = __hip_atomic_load(flow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(v) != 0;
+  }
   __device__ __forceinline__ void give_up() {
     if ((threadIdx.x & 63) == 0) { __hip_atomic_store(flow + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); report_status(status, SFM_E_HIP, -2); }
     dead = true;
@@ -129,13 +137,13 @@ struct FlowWait {
   __device__ __forceinline__ void wait(int i0, int i1 = -1, int i2 = -1, int i3 = -1) {
     if (dead) return;
     const int lane = threadIdx.x & 63;
-    const int mine = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : lane == 3 ? i3 : (lane == 63 ? 2 : -1);
+    const int mine = lane == 0 ? i0 : lane == 1 ? i1 : lane == 2 ? i2 : lane == 3 ? i3 : -1;
     for (unsigned spins = 0;; ++spins) {
       unsigned v = epoch;
       if (mine >= 0) v = __hip_atomic_load(flow + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long miss = __ballot(lane < 4 && mine >= 0 && v != epoch);
+      const unsigned long long miss = __ballot(mine >= 0 && v != epoch);
       if (!miss) break;
-      if (__builtin_amdgcn_readlane(v, 63) != 0 || spins > kFlowSpinLimit) { give_up(); break; }
+      if ((spins & 63) == 63 && (aborted() || spins > kFlowSpinLimit)) { give_up(); break; }
       __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the compiler from hoisting loads above the poll
@@ -162,13 +170,11 @@ struct FlowWait {
     for (unsigned spins = 0;; ++spins) {
       unsigned v = epoch;
       if (mine) v = __hip_atomic_load(flow + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned ab = 0;
-      if (lane == 63) ab = __hip_atomic_load(flow + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long miss = __ballot(mine && v != epoch);
       const unsigned m16 = (unsigned)((miss | (miss >> 16) | (miss >> 32)) & 0xffffu);
       have = m16 ? __builtin_ctz(m16) : n;
       if (have >= need) break;
-      if (__builtin_amdgcn_readlane(ab, 63) != 0 || spins > kFlowSpinLimit) { give_up(); have = n; break; }
+      if ((spins & 63) == 63 && (aborted() || spins > kFlowSpinLimit)) { give_up(); have = n; break; }
       __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -641,8 +647,8 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
   }
 }
 
-// Workgroup 0 is the chain; workgroup b >= 1 takes tasks b-1, b-1 + (grid-1), ... of the table (sorted by column: a task waits
-// only for tasks of earlier columns, so every workgroup's list can be run in order once all workgroups are resident).
+// Workgroup 0 is the chain; the others take the tasks of the table one after the other (sorted by column: a task waits only for
+// tasks before it).
 __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda, int cur) {
   extern __shared__ __attribute__((aligned(16))) double flow_sm[];
   const int tid = threadIdx.x;
@@ -660,7 +666,17 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   if (blockIdx.x == 0) {
     flow_chain(c, d, lambda);
   } else {
-    for (int t = blockIdx.x - 1; t < ntasks; t += gridDim.x - 1) {
+    // Tasks are TAKEN in table order (one agent-scope ticket per task), not dealt by workgroup index: a task waits only for tasks
+    // earlier in the table, and those have been taken by workgroups that are running -- so the launch makes progress with any
+    // number of resident workgroups (two problems on two streams, several ranks rehearsed on one GPU), not only when all of
+    // its workgroups hold a CU at the same time.
+    int* slot = c.smi + 20;
+    const bool dealt = (d.debug & 4096) != 0;      // SFM_OPT_DEBUG bit 4096 (A/B only): tasks dealt by workgroup index; needs every workgroup resident
+    for (int round = 0;; ++round) {
+      if (tid == 0) *slot = dealt ? (int)blockIdx.x - 1 + round * ((int)gridDim.x - 1) : (int)__hip_atomic_fetch_add(flow + kFlowTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int t = *slot;      // every task below passes a barrier before this word is written again
+      if (t >= ntasks) break;
       const FlowTask tk = tasks[t];
       switch (tk.type) {
         case FLOW_T1: flow_task_t1(c, tk.i, tk.k); break;
@@ -680,10 +696,11 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   // the last workgroup to leave closes the epoch
   __syncthreads();
   if (tid == 0) {
-    const unsigned done = __hip_atomic_fetch_add(flow + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned done = __hip_atomic_fetch_add(flow + kFlowDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {
-      __hip_atomic_store(flow + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flow + kFlowDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(flow + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flow + kFlowTicket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(flow, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

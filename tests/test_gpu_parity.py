@@ -453,6 +453,39 @@ def test_ba_data_flow_solve_is_bitwise_repeatable(hip, sfm, n_cams):
         noise.get_state()
 
 
+def test_ba_data_flow_solves_on_four_streams_share_the_chip(hip, sfm):
+    """Four problems of 120 cameras enqueue their iterations on four streams at once: 4 x 225 workgroups that each want a CU of
+    their own meet 256 CUs, so no launch has all its workgroups resident.  Tasks are taken by ticket in table order (a task
+    waits only for tasks taken before it), so every launch advances with whatever share of the chip it holds; the results are
+    those of the same problems run one after the other, bit for bit in deterministic mode."""
+    import torch
+    sc = [sfm.scenes.make_scene(120, 1500, 0.2, seed=40 + q) for q in range(4)]
+    uv = [sfm.geometry.normalise_pixels(x.uv_pix, x.intrinsic) for x in sc]
+    alone = []
+    for x, u in zip(sc, uv):
+        with hip.BaProblem(x.n_cams, x.pt_ptr, x.cam_idx, u) as prob:
+            prob.set_option(hip.OPT_DETERMINISTIC, 1)
+            prob.set_state(x.cams_init, x.pts_init)
+            prob.iterate(5.0, 4)
+            alone.append(prob.get_state())
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    probs = [hip.BaProblem(x.n_cams, x.pt_ptr, x.cam_idx, u) for x, u in zip(sc, uv)]
+    try:
+        for prob, st, x in zip(probs, streams, sc):
+            prob.set_option(hip.OPT_DETERMINISTIC, 1)
+            prob.set_stream(st.cuda_stream)
+            prob.set_state(x.cams_init, x.pts_init)
+        for rep in range(4):                  # one iteration per problem and round: the four queues stay full together
+            for prob in probs:
+                prob.iterate(5.0, 1)
+        for prob, want in zip(probs, alone):
+            cams, pts = prob.get_state()
+            assert np.array_equal(cams, want[0]) and np.array_equal(pts, want[1])
+    finally:
+        for prob in probs:
+            prob.close()
+
+
 @pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
 def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
     """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;
