@@ -453,6 +453,30 @@ def test_ba_data_flow_solve_is_bitwise_repeatable(hip, sfm, n_cams):
         noise.get_state()
 
 
+def test_ba_data_flow_solve_gives_up_instead_of_hanging(hip, oracle, sfm):
+    """Every wait of the data-flow launch is bounded.  With SFM_OPT_DEBUG bit 8192 the chain never announces W_1: the tasks that
+    need it give up after 20 000 polls, raise the abort word, every other wait of the launch ends, the launch drains and the
+    state read reports SFM_E_HIP -- no hang, no fault.  The same handle then solves correctly again (flags carry the solve's
+    epoch, the abandoned solve closed its own)."""
+    import time
+    sc = sfm.scenes.make_scene(40, 1200, 0.5, seed=8)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_DEBUG, 8192)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        t0 = time.time()
+        prob.iterate(5.0, 1)
+        with pytest.raises(hip.SfmHipError):
+            prob.get_state()
+        assert time.time() - t0 < 20.0
+        prob.set_option(hip.OPT_DEBUG, 0)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        prob.iterate(5.0, 2)
+        cams, pts = prob.get_state()
+    assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+
+
 def test_ba_data_flow_solves_on_four_streams_share_the_chip(hip, sfm):
     """Four problems of 120 cameras enqueue their iterations on four streams at once: 4 x 225 workgroups that each want a CU of
     their own meet 256 CUs, so no launch has all its workgroups resident.  Tasks are taken by ticket in table order (a task
