@@ -243,12 +243,13 @@ __device__ __forceinline__ void flow_row_sum(FlowCtx& c, f64x4& acc, int arow, i
 
 // second half of a plain task: T^T (accumulator layout) -> LDS -> L^T = W_k T^T -> its k-interleaved block in global memory
 template <int OWN>
-__device__ __forceinline__ void flow_finish(FlowCtx& c, const f64x4& t, int own, int k) {
+__device__ __forceinline__ void flow_finish(FlowCtx& c, const f64x4& t, int own, int k, unsigned long long* stamp = nullptr) {
   double* Tx = c.sm + FS_B;
   const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk);
   ctile_st_lds(Tx, coff, t);
   __syncthreads();
   c.w.wait(flow_fw(c.nbk, k));
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
   double a[8], b[8];
   op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
   op_lds(Tx, c.sy, c.lr, c.lk, b);
@@ -266,10 +267,14 @@ __device__ __forceinline__ void flow_finish(FlowCtx& c, const f64x4& t, int own,
 }
 
 __device__ __forceinline__ void flow_task_t1(FlowCtx& c, int i, int k) {
+  unsigned long long* stamp = (c.stamps && k == i - 4) ? c.stamps + 128 + 8 * i : nullptr;      // the block the closer of row i waits for last
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
   const f64x4 s = ctile_ld_S(c.redp + red_blk_base(i, k), c.sx, c.sy, c.lr, c.lk);
   f64x4 acc = {0, 0, 0, 0};
   flow_row_sum<0>(c, acc, k, i, 0, k);
-  flow_finish<0>(c, s - acc, i, k);
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  flow_finish<0>(c, s - acc, i, k, stamp);
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // hand-over block (i, i-1) through column i-4
@@ -293,13 +298,16 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   const f64x4 s0 = ctile_ld_S(c.redp + red_blk_base(i, i - 2), c.sx, c.sy, c.lr, c.lk);
   const f64x4 s2 = ctile_ld_S(c.redp + red_blk_base(i, i), c.sx, c.sy, c.lr, c.lk);
   f64x4 accT = {0, 0, 0, 0}, acc0 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-  unsigned long long* stamp = c.stamps ? c.stamps + 640 + 8 * i : nullptr;
-  if (stamp) stamp[0] = __builtin_amdgcn_s_memtime();
+  unsigned long long* stamp = c.stamps ? c.stamps + 640 + 8 * i : nullptr;      // 100 MHz clock (s_memrealtime): comparable across workgroups
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  // The sums through column k-1 -- except ONE term: L[i-2][k-1] is the block (r, r-2) of the chain's row r = i-2, which the chain
+  // forms during step k and announces together with W_k (the cross-workgroup timeline showed the closer still summing 1.9 us
+  // after W_k was out because it waited for that flag with all three sums).  That term joins the two last ones behind W_k.
   int ready = 0;
-  for (int m = 0; m < k;) {
+  for (int m = 0; m < k - 1;) {            // columns 0 .. k-2: all three sums
     if (m >= ready) {
       const int ws = m & ~15;
-      ready = ws + c.w.wait_terms(flow_fl(nbk, k, ws), flow_fl(nbk, i - 2, ws), flow_fl(nbk, i, ws), 3, min(16, k - ws), m - ws + 1);
+      ready = ws + c.w.wait_terms(flow_fl(nbk, k, ws), flow_fl(nbk, i - 2, ws), flow_fl(nbk, i, ws), 3, min(16, k - 1 - ws), m - ws + 1);
     }
     const int n = min(ready - m, 2);
     double b[2][8], at[2][8], a0[2][8], a2[2][8];
@@ -316,25 +324,41 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
       if (q < n) { mfma8(accT, at[q], b[q]); mfma8(acc0, a0[q], b[q]); mfma8(acc2, a2[q], b[q]); }
     m += n;
   }
+  double bl[8];      // operand tile of L[i][k-1], kept for the deferred term
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bl[q] = 0;
+  if (k >= 1) {                            // column k-1: the sums of L[i][k] and of (i, i)
+    c.w.wait(flow_fl(nbk, k, k - 1), flow_fl(nbk, i, k - 1));
+    if (stamp) stamp[6] = __builtin_amdgcn_s_memrealtime();
+    double at[8], a2[8];
+    op_sc1(c.red, red_blk_base(i, k - 1), c.sy, c.lr, c.lk, bl);
+    op_sc1(c.red, red_blk_base(k, k - 1), c.sx, c.lr, c.lk, at);
+    op_sc1(c.red, red_blk_base(i, k - 1), c.sx, c.lr, c.lk, a2);
+    mfma8(accT, at, bl);
+    mfma8(acc2, a2, bl);
+  }
   double* Tx = c.sm + FS_B;
   double* Lx = c.sm + FS_B + kBlk;
   ctile_st_lds(Tx, coff, sT - accT);
   __syncthreads();
-  if (stamp) stamp[1] = __builtin_amdgcn_s_memtime();
-  // W_k is published ~1 300 cycles before L[i-2][k]: its load travels while the second flag is polled
-  double a[8], b[8], a0[8];
-  c.w.wait(flow_fw(nbk, k));
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  double a[8], b[8], a0[8], a0p[8];
+  // W_k and L[i-2][k-1] are announced together; L[i-2][k] ~0.6 us later: the loads of the first two travel while it is polled
+  if (k >= 1) c.w.wait(flow_fw(nbk, k), flow_fl(nbk, i - 2, k - 1)); else c.w.wait(flow_fw(nbk, k));
+  if (stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
   op_sc1(c.ldiag, (size_t)k * kBlk, c.sx, c.lr, c.lk, a);
+  if (k >= 1) op_sc1(c.red, red_blk_base(i - 2, k - 1), c.sx, c.lr, c.lk, a0p);
   c.w.wait(flow_fl(nbk, i - 2, k));
-  if (stamp) stamp[2] = __builtin_amdgcn_s_memtime();
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
   op_sc1(c.red, red_blk_base(i - 2, k), c.sx, c.lr, c.lk, a0);
   op_lds(Tx, c.sy, c.lr, c.lk, b);
   f64x4 o = {0, 0, 0, 0};
   mfma8(o, a, b);
   ctile_st_sc1(c.red, red_blk_base(i, k), coff, o);
   ctile_st_lds(Lx, coff, o);
+  if (k >= 1) mfma8(acc0, a0p, bl);      // the deferred term
   __syncthreads();
-  if (stamp) stamp[3] = __builtin_amdgcn_s_memtime();
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
   op_lds(Lx, c.sy, c.lr, c.lk, b);
   op_lds(Lx, c.sx, c.lr, c.lk, a);
   mfma8(acc0, a0, b);
@@ -348,7 +372,7 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
     flow_publish(c.flow, flow_fh(nbk, i, 0), c.epoch);
     flow_publish(c.flow, flow_fh(nbk, i, 2), c.epoch);
   }
-  if (stamp) stamp[4] = __builtin_amdgcn_s_memtime();
+  if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
 }
 
 __device__ __forceinline__ void flow_task_rhs(FlowCtx& c, int k) {
@@ -507,6 +531,7 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
     const double* LBprev = sm + FS_LB + ((j & 1) ^ 1) * kBlk;
     double* B0 = sm + FS_B, *B1 = sm + FS_B + kBlk, *B2 = sm + FS_B + 2 * kBlk;
     if (stamp) stamp[8 * j + 0] = __builtin_amdgcn_s_memtime();
+    if (stamp && tid == 256) stamp[384 + 8 * j + 0] = __builtin_amdgcn_s_memrealtime();
     if (grp == 0) {
       // ---- elimination of [D_j; I]
       const int row = lane & (NB - 1);
@@ -532,7 +557,7 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
           for (int h = 0; h < 2; ++h) pf[t][h] = ld2_sc1(c.red, red_blk_base(r, r - 2 + t) + 2 * (u0 + 256 * h));
         op_sc1(c.red, red_blk_base(r, r - 3), sy, lr, lk, pfb);
       }
-      if (stamp) stamp[8 * j + 5] = __builtin_amdgcn_s_memtime();
+      if (stamp) { stamp[8 * j + 5] = __builtin_amdgcn_s_memtime(); stamp[384 + 8 * j + 1] = __builtin_amdgcn_s_memrealtime(); }
       flow_lds_wait(c2_done, j);            // step j-1 has read the last of B0..B2
       if (r >= 3) {
 #pragma unroll
@@ -545,7 +570,7 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
         ctile_st_lds(B2, coff, ctile_ld_S(c.redp + red_blk_base(r, r), sx, sy, lr, lk));
       }
       pf_ok = false;
-      if (stamp) stamp[256 + 8 * j + 0] = __builtin_amdgcn_s_memtime();
+      if (stamp) { stamp[256 + 8 * j + 0] = __builtin_amdgcn_s_memtime(); stamp[384 + 8 * j + 2] = __builtin_amdgcn_s_memrealtime(); }
       flow_group_sync(pctr, ptarget);
       if (stamp) stamp[256 + 8 * j + 1] = __builtin_amdgcn_s_memtime();
       f64x4 acc1 = {0, 0, 0, 0};
@@ -636,13 +661,14 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
         flow_publish(c.flow, flow_fw(nbk, j), c.epoch);
         flow_publish(c.flow, flow_fx(nbk, j, j), c.epoch);
         if (has_r && r >= 2) flow_publish(c.flow, flow_fl(nbk, r, r - 2), c.epoch);      // stored by the preparation above, drained here
+        if (stamp) stamp[384 + 8 * j + 3] = __builtin_amdgcn_s_memrealtime();
       }
       if (!has_r) break;
       flow_lds_wait(la_ready, j + 1);
       push_block(LAcur, c.red, red_blk_base(r, j));
       flow_drain();
       flow_group_sync(pctr, ptarget);
-      if (tid == 256) flow_publish(c.flow, flow_fl(nbk, r, j), c.epoch);
+      if (tid == 256) { flow_publish(c.flow, flow_fl(nbk, r, j), c.epoch); if (stamp) stamp[384 + 8 * j + 4] = __builtin_amdgcn_s_memrealtime(); }
       if (stamp) stamp[8 * j + 7] = __builtin_amdgcn_s_memtime();
     }
   }

@@ -30,10 +30,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "stamps":
         print("prep %2d (rel. to step start): seen %6d  regs->LDS %6d  sync %6d  d'+trsm %6d  sync %6d  done %6d" % (
             j, pr[j, 5] - el[j, 0], pd[j, 0] - el[j, 0], pd[j, 1] - el[j, 0], pd[j, 3] - el[j, 0], pd[j, 4] - el[j, 0], pr[j, 6] - el[j, 0]))
     print("chain total ticks", el[10, 2] - t0)
-    cl = raw[640:768].reshape(16, 8)
-    for i in range(3, 11):
-        print("closer %2d (needs W_%d, hand-over wanted at step %d start = %6d): start %6d  sums done %6d  W seen %6d  L formed %6d  published %6d   [chain: W_%d ready %6d]" % (
-            i, i - 3, i - 1, el[i - 1, 0] - t0, cl[i, 0] - t0, cl[i, 1] - t0, cl[i, 2] - t0, cl[i, 3] - t0, cl[i, 4] - t0, i - 3, el[i - 3, 2] - t0))
+    rt = raw[896:1024].reshape(16, 8)      # chain, constant 100 MHz clock (s_memrealtime): [0] step start, [1] preparation starts, [2] row in LDS, [3] W_j announced, [4] L[j+1][j] announced
+    cl = raw[640:768].reshape(16, 8)       # closer of row i, same clock: [0] start, [6] last term of the sums there, [1] sums done, [5] W seen, [2] L[i-2][k] seen, [3] L formed, [4] hand-over announced
+    t1 = raw[128:256].reshape(16, 8)       # task L[i][i-4], same clock: [0] start, [1] sum done, [2] W seen, [3] announced
+    r0 = rt[0, 0]
+    us = lambda v: (int(v) - int(r0)) / 100.0
+    print("cross-workgroup timeline, us on the 100 MHz clock since the chain's first step")
+    for i in range(4, 11):
+        k = i - 3
+        print("  row %2d | chain: W_%d announced %6.2f, W_%d announced %6.2f, L[%d][%d] announced %6.2f | task L[%d][%d]: sum done %6.2f, W_%d seen %6.2f, announced %6.2f | closer: last term there %6.2f, sums done %6.2f, W_%d seen %6.2f, L seen %6.2f, L formed %6.2f, hand-over announced %6.2f | chain step %d: start %6.2f, preparation starts %6.2f, row in LDS %6.2f" % (
+            i, k - 1, us(rt[k - 1, 3]), k, us(rt[k, 3]), k + 1, k, us(rt[k, 4]), i, k - 1, us(t1[i, 1]), k - 1, us(t1[i, 2]), us(t1[i, 3]),
+            us(cl[i, 6]), us(cl[i, 1]), k, us(cl[i, 5]), us(cl[i, 2]), us(cl[i, 3]), us(cl[i, 4]), i - 1, us(rt[i - 1, 0]), us(rt[i - 1, 1]), us(rt[i - 1, 2])))
     sys.exit(0)
 
 oracle = importlib.import_module("sfm_oracle")
