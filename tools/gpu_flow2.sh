@@ -1,6 +1,6 @@
 #!/bin/bash
 out=gpurun_out/flow2; mkdir -p $out; export TMPDIR=/tmp; rm -f $out/*
-timeout -k 10 300 python tools/flow_check.py > $out/check.txt 2>&1; echo "check rc=$?" | tee $out/steps.log; grep -v amdgpu $out/check.txt | tail -4
+timeout -k 10 300 python tools/flow_check.py > $out/check.txt 2>&1; echo "check rc=$?" | tee $out/steps.log; grep -v amdgpu $out/check.txt | tail -2
 [ "$(tail -1 $out/steps.log)" = "check rc=0" ] || exit 1
 timeout -k 10 120 python tools/flow_check.py stamps 0 > $out/stamps_0.txt 2>&1; echo "stamps rc=$?" | tee -a $out/steps.log; grep "^step\|^chain" $out/stamps_0.txt
 for dbg in 0 1024 0; do
