@@ -57,7 +57,7 @@ constexpr int FS_LA = 6208;               // [2][1024] L[j+1][j] of this and the
 constexpr int FS_LB = 8256;               // [2][1024] L[r][r-2] of this and the previous step
 constexpr int FS_B = 10304;               // [3][1024] the row being taken over: (r, r-2), (r, r-1), (r, r); tasks: T and L
 constexpr int FS_XL = 13376;              // [1024] X_j in the operand layout, for the preparation waves to publish
-constexpr int FS_INT = 14400;             // ints: elimination flag, the two group-barrier counters, the two step counters between the groups
+constexpr int FS_INT = 14400;             // ints: [0..4] the chain's elimination flag, group-barrier counters and step counters; task workgroups: [15] last-arriver flag of dp, [20] ticket
 constexpr int FS_TOTAL = 14416;
 constexpr size_t kFlowLdsBytes = FS_TOTAL * sizeof(double);
 
