@@ -8,22 +8,24 @@
 // (chol_trsm_cols: L_jj and X_j = L_jj^-T in one instruction stream), forms L[j+1][j] = T W_j^T and D_j+1 -= L L^T on the
 // matrix pipe out of LDS, and goes on.  Everything else — the blocks of L more than two block rows below the diagonal, the
 // right-hand side, the identity rows that leave X = L^-T behind for ba_inv_apply — is plain matrix-pipe work: one TASK per
-// block, LEFT-looking (S_ik - sum_m L[i][m] L[k][m]^T, then the product with W_k = L_kk^-1), dealt to the other workgroups
-// of the launch in column order.  Blocks travel through global memory: write-through (sc1) stores, one flag word per block,
+// block, LEFT-looking (S_ik - sum_m L[i][m] L[k][m]^T, then the product with W_k = L_kk^-1), taken by the other workgroups
+// of the launch one after the other in column order (a ticket per task).  Blocks travel through global memory: write-through (sc1) stores, one flag word per block,
 // sc1 loads on the consuming side (MI355X_MICROARCH.md, inter-workgroup visibility; every workgroup of this launch owns its
 // CU: 113 KB of LDS).
 //
 // Who computes what (the chain keeps the two sub-diagonals to itself):
-//   chain, step j:   elimination waves (0-3): [D_j; I] -> X_j -> xinv(j, j), W_j = X_j^T -> ldiag[j]; then
-//                    L[j+1][j] = T W_j^T (TRSM as a product), D_j+1 -= L[j+1][j] L[j+1][j]^T.
+//   chain, step j:   elimination waves (0-3, LDS only): [D_j; I] -> X_j, W_j = X_j^T; then L[j+1][j] = T W_j^T (TRSM as a product),
+//                    D_j+1 -= L[j+1][j] L[j+1][j]^T.
 //                    preparation waves (4-7), concurrently with the elimination, row r = j+1: take over the blocks
-//                    (r, r-2), (r, r-1), (r, r), L[r][r-2] = T W_j-1^T, and apply columns r-3 / r-2 to (r, r-1) and column
-//                    r-2 to (r, r).
+//                    (r, r-2), (r, r-1), (r, r) (fetched a step ahead), L[r][r-2] = T W_j-1^T, and apply columns r-3 / r-2 to
+//                    (r, r-1) and column r-2 to (r, r); behind the elimination they publish X_j -> xinv(j, j), W_j -> ldiag[j], L[j+1][j].
 //   tasks of block row i >= 3:  L[i][k] for k <= i-4; the "closer" L[i][i-3] together with the hand-over blocks (i, i-2) and
-//                    (i, i) through column i-3 (sums through column i-4 formed before W_i-3 exists, the last terms out of LDS);
+//                    (i, i) through column i-3 (sums through column i-4 formed before W_i-3 exists -- but for the one term that needs
+//                    the chain's L[i-2][i-4], announced with W_i-3 --, the last terms out of LDS);
 //                    the hand-over block (i, i-1) through column i-4 — levels chosen so that no hand-over waits for a block
 //                    the chain publishes later than W_i-3.
-//   tasks of the rhs row and of the identity rows e = 0 .. nbk-2: the same recurrence with their own blocks.
+//   tasks of the rhs row and of the identity rows e = 0 .. nbk-2: the same recurrence with their own blocks; the task that finishes
+//                    an identity row forms its part of dp = X y, the last one to arrive updates the cameras.
 // Every block is produced by exactly one task with a fixed summation order: the result does not depend on timing or placement.
 // All products are formed TRANSPOSED (the 16x16x4 accumulator layout of M^T is the operand layout of M: rows lk + 4g), so a
 // block goes accumulator -> k-interleaved block (red_lblk_off) with two 16-byte stores per tile and comes back as an A or
@@ -32,7 +34,7 @@
 
 namespace sfm {
 
-constexpr int kFlowMaxNbk = kInvRowsMaxNbk;      // wherever the identity rows are carried (dp = X y by ba_inv_apply)
+constexpr int kFlowMaxNbk = kInvRowsMaxNbk;      // wherever xinv is allocated (X = L^-T for dp = X y): 52 block columns, 237 cameras
 constexpr int kFlowHdr = 128;        // header words of BaDev::flow, the hot ones on 128-byte lines of their own: [0] epoch of the last finished solve,
                                      // [2] abort (read-mostly, polled rarely), [32] workgroups done, [64] tasks taken (one atomic per task); flags from [128]
 constexpr int kFlowDone = 32, kFlowTicket = 64;
