@@ -424,6 +424,26 @@ def test_ba_data_flow_solve_against_column_steps_and_oracle(hip, oracle, sfm, n_
     assert rel(out[0][0], out[1][0]) < 1e-11 and rel(out[0][1], out[1][1]) < 1e-11
 
 
+def test_ba_data_flow_solve_random_shapes(hip, oracle, sfm):
+    """Sixteen seeded random shapes between 9 and 140 cameras (every number of block columns has its own task table, its own
+    first closer, its own ragged last block of 7 V mod 32 rows), random visibility and damping, 1-3 iterations, against the oracle."""
+    rng = np.random.default_rng(20240)
+    for case in range(16):
+        n_cams = int(rng.integers(9, 141))
+        n_pts = int(rng.integers(300, 1500))
+        vis = float(rng.uniform(max(0.08, 4.0 / n_cams), 0.9))
+        lam = float(rng.choice([0.5, 5.0, 50.0]))
+        iters = int(rng.integers(1, 4))
+        sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=700 + case)
+        uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+        want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, lam, iters)
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(lam, iters)
+            cams, pts = prob.get_state()
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL, (case, n_cams, n_pts, vis, lam, iters, rel(cams, want_c), rel(pts, want_p))
+
+
 @pytest.mark.parametrize("n_cams", [12, 50, 120])
 def test_ba_data_flow_solve_is_bitwise_repeatable(hip, sfm, n_cams):
     """Every block of the data-flow solve is produced by one task with a fixed summation order, whatever the timing of the
