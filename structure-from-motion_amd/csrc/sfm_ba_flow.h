@@ -491,7 +491,7 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
   int* c2_done = c.smi + 4;      // steps whose D_j+1 is formed (the row buffers B0..B2 are free again)
   int ptarget = 0, etarget = 0;
   const int coff = ctile_off(sx, sy, lr, lk);
-  unsigned long long* stamp = (d.stamps && (tid == 0 || tid == 256)) ? d.stamps + (tid == 0 ? 0 : 512) : nullptr;
+  unsigned long long* stamp = (d.stamps && nbk <= 16 && (tid == 0 || tid == 256)) ? d.stamps + (tid == 0 ? 0 : 512) : nullptr;
 
   // D(a, kappa) of diagonal block `blk` from accumulator tile (sx, sy) of D^T: + lambda, identity on the padding
   auto put_d = [&](int blk, const f64x4& v) {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   c.lane = tid & 63; c.lr = c.lane & 15; c.lk = c.lane >> 4;
   c.gw = (tid >> 6) & 3; c.sx = c.gw >> 1; c.sy = c.gw & 1;
   c.w = FlowWait{flow, c.epoch, d.status, false, (d.debug & 8192) ? 20000u : kFlowSpinLimit};
-  c.stamps = (d.stamps && tid == 0) ? d.stamps : nullptr;
+  c.stamps = (d.stamps && tid == 0 && d.nbk <= 16) ? d.stamps : nullptr;      // the 1024 stamp slots are laid out for up to 16 block columns
   if (blockIdx.x == 0) {
     flow_chain(c, d, lambda);
   } else {
