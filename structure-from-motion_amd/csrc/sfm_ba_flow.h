@@ -11,7 +11,7 @@
 // block, LEFT-looking (S_ik - sum_m L[i][m] L[k][m]^T, then the product with W_k = L_kk^-1), taken by the other workgroups
 // of the launch one after the other in column order (a ticket per task).  Blocks travel through global memory: write-through (sc1) stores, one flag word per block,
 // sc1 loads on the consuming side (MI355X_MICROARCH.md, inter-workgroup visibility; every workgroup of this launch owns its
-// CU: 113 KB of LDS).
+// CU: 121 KB of LDS).
 //
 // Who computes what (the chain keeps the two sub-diagonals to itself):
 //   chain, step j:   elimination waves (0-3, LDS only): [D_j; I] -> X_j, W_j = X_j^T; then L[j+1][j] = T W_j^T (TRSM as a product),
@@ -59,8 +59,9 @@ constexpr int FS_LA = 6208;               // [2][1024] L[j+1][j] of this and the
 constexpr int FS_LB = 8256;               // [2][1024] L[r][r-2] of this and the previous step
 constexpr int FS_B = 10304;               // [3][1024] the row being taken over: (r, r-2), (r, r-1), (r, r); tasks: T and L
 constexpr int FS_XL = 13376;              // [1024] X_j in the operand layout, for the preparation waves to publish
-constexpr int FS_INT = 14400;             // ints: [0..4] the chain's elimination flag, group-barrier counters and step counters; task workgroups: [15] last-arriver flag of dp, [20] ticket
-constexpr int FS_TOTAL = 14416;
+constexpr int FS_XM2 = 14400;             // [32][33] the second X_j row buffer
+constexpr int FS_INT = 15456;             // ints: [0..4] the chain's elimination flag, group-barrier counters and step counters; task workgroups: [15] last-arriver flag of dp, [20] ticket
+constexpr int FS_TOTAL = 15472;
 constexpr size_t kFlowLdsBytes = FS_TOTAL * sizeof(double);
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -462,10 +463,10 @@ __device__ __forceinline__ void flow_task_dp(FlowCtx& c, const BaDev& d, int e, 
 
 // ---------------------------------------------------------------------------------------------
 // The chain.  512 threads.  Waves 0-3 (raised priority) eliminate and never touch global memory: elimination -> X_j rows in LDS ->
-// [all waves: X_j, W_j = X_j^T into operand layout, LDS] -> L[j+1][j] -> D_j+1 -> next elimination, with barriers of their own
-// group in between.  Waves 4-7 do everything that waits for memory: they publish what the elimination waves leave in LDS (X_j,
-// W_j, L[j+1][j]: copy, drain, flag) and prepare the next row.  The two groups meet at two workgroup barriers per step (X_j rows
-// complete / operand blocks complete) and hand each other the LDS buffers through two step counters.
+// L[j+1][j] (operand tile of W_j read straight from those rows) -> D_j+1 -> next elimination, with barriers of their own group in
+// between.  Waves 4-7 do everything that waits for memory: they publish what the elimination waves leave in LDS (X_j,
+// W_j in the operand layout, L[j+1][j]: copy, drain, flag) and prepare the next row.  The two groups meet at ONE workgroup barrier per
+// step (X_j rows complete, row r prepared) and hand each other the LDS buffers through two step counters.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void flow_lds_wait(const int* word, int value) {
   while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < value) __builtin_amdgcn_s_sleep(1);
@@ -481,7 +482,6 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
   const int sx = c.sx, sy = c.sy, lr = c.lr, lk = c.lk, gw = c.gw;
   double* sm = c.sm;
   double(*Dm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_DM);
-  double(*Xm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + FS_XM);
   f64x2(*xy)[64] = reinterpret_cast<f64x2(*)[64]>(sm + FS_XY);
   double* Xl = sm + FS_XL;
   int* eflag = c.smi;            // chol_trsm_cols: pair-steps published
@@ -532,6 +532,8 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
     double* LBcur = sm + FS_LB + (j & 1) * kBlk;
     const double* LBprev = sm + FS_LB + ((j & 1) ^ 1) * kBlk;
     double* B0 = sm + FS_B, *B1 = sm + FS_B + kBlk, *B2 = sm + FS_B + 2 * kBlk;
+    // X_j rows of the elimination: two buffers in turn (the preparation waves read step j's while the elimination waves are in step j+1)
+    double(*Xm)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(sm + ((j & 1) ? FS_XM2 : FS_XM));
     if (stamp) stamp[8 * j + 0] = __builtin_amdgcn_s_memtime();
     if (stamp && tid == 256) stamp[384 + 8 * j + 0] = __builtin_amdgcn_s_memrealtime();
     if (grp == 0) {
@@ -618,21 +620,15 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
     }
     __syncthreads();                                                  // B: X_j rows in Xm, row r prepared
     if (stamp) stamp[8 * j + 1] = __builtin_amdgcn_s_memtime();
-    {
-      // X_j and W_j = X_j^T into the operand layout (LDS): W_j for this step's TRSM and the next step's preparation, both for the
-      // preparation waves to publish (ldiag[j]: the tasks; xinv(j, j): ba_inv_apply and the tasks of identity row j)
-      const int m = tid >> 7, q = (tid >> 5) & 3, col = tid & 31, kap = 8 * m + q;
-      const int off = m * 256 + q * 64 + 2 * col;
-      *reinterpret_cast<f64x2*>(Wcur + off) = f64x2{Xm[kap][col], Xm[kap + 4][col]};
-      *reinterpret_cast<f64x2*>(Xl + off) = f64x2{Xm[col][kap], Xm[col][kap + 4]};
-    }
-    __syncthreads();                                                  // C: operand blocks complete
     if (stamp) stamp[8 * j + 2] = __builtin_amdgcn_s_memtime();
     if (grp == 0) {
       if (!has_r) break;
-      // L[r][j]^T = W_j T^T
+      // L[r][j]^T = W_j T^T with W_j(c, kappa) = X_j(kappa, c) taken straight from the rows the elimination left (8-byte reads, two
+      // lanes per bank pair): the elimination waves do not wait for the operand layout of X_j / W_j, which only the
+      // preparation waves need (publishing, the next step's product)
       double a[8], b[8];
-      op_lds(Wcur, sx, lr, lk, a);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) a[ks] = Xm[lk + 4 * ks][16 * sx + lr];
       op_lds(B1, sy, lr, lk, b);
       f64x4 o = {0, 0, 0, 0};
       mfma8(o, a, b);
@@ -653,7 +649,19 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
       flow_lds_post(c2_done, j + 1);
       if (stamp) stamp[8 * j + 4] = __builtin_amdgcn_s_memtime();
     } else {
-      // publish X_j, W_j, then L[r][j] as soon as the elimination waves have it
+      // X_j and W_j = X_j^T into the operand layout (LDS): W_j for the next step's preparation, both to be published (ldiag[j]: the
+      // tasks; xinv(j, j): ba_inv_apply and the tasks of identity row j), then L[r][j] as soon as the elimination waves have it
+      {
+        const int u0 = tid - 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int idx = u0 + 256 * h, m = idx >> 7, q = (idx >> 5) & 3, col = idx & 31, kap = 8 * m + q;
+          const int off = m * 256 + q * 64 + 2 * col;
+          *reinterpret_cast<f64x2*>(Wcur + off) = f64x2{Xm[kap][col], Xm[kap + 4][col]};
+          *reinterpret_cast<f64x2*>(Xl + off) = f64x2{Xm[col][kap], Xm[col][kap + 4]};
+        }
+      }
+      flow_group_sync(pctr, ptarget);
       push_block(Xl, c.xinv, red_blk_base(j, j));
       push_block(Wcur, c.ldiag, (size_t)j * kBlk);
       flow_drain();
