@@ -23,8 +23,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "stamps":
     el, pr = raw[:128].reshape(16, 8), raw[512:640].reshape(16, 8)
     t0 = el[0, 0]
     for j in range(11):
-        print("step %2d  start %6d  elim+prep %5d  transpose %4d  trsm %4d  syrk %4d | prep: hand-over seen %6d, done %6d, L published %6d (rel. to step start)" % (
-            j, el[j, 0] - t0, el[j, 1] - el[j, 0], el[j, 2] - el[j, 1], el[j, 3] - el[j, 2], el[j, 4] - el[j, 3], pr[j, 5] - el[j, 0], pr[j, 6] - el[j, 0], pr[j, 7] - el[j, 0]))
+        print("step %2d  start %6d  elimination beside the preparation %5d  L[j+1][j] %4d  D_j+1 %4d | preparation: starts %6d, done %6d, L[j+1][j] announced %6d (rel. to step start)" % (
+            j, el[j, 0] - t0, el[j, 1] - el[j, 0], el[j, 3] - el[j, 2], el[j, 4] - el[j, 3], pr[j, 5] - el[j, 0], pr[j, 6] - el[j, 0], pr[j, 7] - el[j, 0]))
     pd = raw[768:896].reshape(16, 8)
     for j in range(10):
         print("prep %2d (rel. to step start): seen %6d  regs->LDS %6d  sync %6d  d'+trsm %6d  sync %6d  done %6d" % (
