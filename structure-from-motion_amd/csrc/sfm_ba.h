@@ -76,7 +76,7 @@ struct BaDev {
                             // through the column steps as extra block rows (sfm_ba_solve.hip); dp = X y is one launch
   int* sync_ctr = nullptr;  // [1] workgroups of ba_inv_apply that have stored their part of dp (self-resetting)
   unsigned* flow = nullptr; // [flow_words(nbk)] epoch / arrival / abort words and one flag per block of the data-flow solve (sfm_ba_flow.h); null beyond kFlowMaxNbk
-  const void* flow_tasks = nullptr;  // [flow_ntasks] FlowTask table of the data-flow solve, sorted by column
+  const void* flow_tasks = nullptr;  // [flow_ntasks] FlowTask table of the data-flow solve, sorted by column (one per device and nbk, owned by sfm_ba_solve.hip)
   int flow_ntasks = 0;
   int debug = 0;            // copy of sfm_ba_problem::debug for kernels that switch on it (diagnostic stamps, code-path switches)
   int* status = nullptr;    // [2] first failure code, camera index

@@ -297,7 +297,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   ba_graph_drop(p);
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
-                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.xinv, d.sync_ctr, d.flow, const_cast<void*>(d.flow_tasks), d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
+                  d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.xinv, d.sync_ctr, d.flow, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
                   p->schur_ws, p->schur_blk_ptr, p->cam_ptr, p->cam_ent, p->cam_pairs, p->rows_table, p->rows_first, p->rows_ws};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)

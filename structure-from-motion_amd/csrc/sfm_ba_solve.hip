@@ -21,6 +21,8 @@
 //                  factors the factorisation left behind, ba_back_update between groups of block rows.
 //   ba_small_solve P <= 56: the whole solve in one single-workgroup launch (whole-matrix multi-wave elimination).
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "sfm_ba.h"
 
@@ -759,15 +761,26 @@ namespace sfm {
 int ba_flow_setup(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   if (d.nbk < 2 || d.nbk > kFlowMaxNbk) return SFM_OK;
-  const std::vector<FlowTask> tasks = flow_build_tasks(d.nbk);
+  // The task table depends on nbk alone: one device copy per (device, nbk) for the life of the process, so that the per-view
+  // sfm_ba_append of the drop-in classes (a new problem object every time) neither allocates nor copies it again.
+  static std::mutex mu;
+  static std::map<long long, std::pair<void*, int>> tables;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const long long key = (long long)ctx().device * 1000 + d.nbk;
+    auto it = tables.find(key);
+    if (it == tables.end()) {
+      const std::vector<FlowTask> tasks = flow_build_tasks(d.nbk);
+      void* tk = nullptr;
+      SFM_HIP(hipMalloc(&tk, sizeof(FlowTask) * std::max<size_t>(1, tasks.size())));
+      if (!tasks.empty()) SFM_HIP(hipMemcpy(tk, tasks.data(), sizeof(FlowTask) * tasks.size(), hipMemcpyHostToDevice));
+      it = tables.emplace(key, std::make_pair(tk, (int)tasks.size())).first;
+    }
+    d.flow_tasks = it->second.first;
+    d.flow_ntasks = it->second.second;
+  }
   SFM_HIP(pool_alloc(reinterpret_cast<void**>(&d.flow), sizeof(unsigned) * flow_words(d.nbk)));
-  void* tk = nullptr;
-  SFM_HIP(pool_alloc(&tk, sizeof(FlowTask) * std::max<size_t>(1, tasks.size())));
-  d.flow_tasks = tk;
-  d.flow_ntasks = (int)tasks.size();
   SFM_HIP(hipMemsetAsync(d.flow, 0, sizeof(unsigned) * flow_words(d.nbk), p->stream));
-  // the table is pageable host memory that dies with this call: a synchronous copy
-  if (!tasks.empty()) SFM_HIP(hipMemcpy(tk, tasks.data(), sizeof(FlowTask) * tasks.size(), hipMemcpyHostToDevice));
   static int attr_device = -1;
   if (attr_device != ctx().device) {
     SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsBytes));
