@@ -761,6 +761,9 @@ namespace sfm {
 int ba_flow_setup(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   if (d.nbk < 2 || d.nbk > kFlowMaxNbk) return SFM_OK;
+  // field switch: SFM_FLOW_SOLVE=0 keeps every problem on the column-step launches (what SFM_OPT_DEBUG bit 1024 does per handle)
+  static const bool enabled = [] { const char* e = getenv("SFM_FLOW_SOLVE"); return !(e && atoi(e) == 0); }();
+  if (!enabled) return SFM_OK;
   // The task table depends on nbk alone: one device copy per (device, nbk) for the life of the process, so that the per-view
   // sfm_ba_append of the drop-in classes (a new problem object every time) neither allocates nor copies it again.
   static std::mutex mu;
