@@ -67,7 +67,7 @@ extern "C" {
                               * contribution (many cameras at low visibility: BASELINE config 4) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 1024 = the column steps of the reduced solve as separate launches (ba_chol_step) where the single data-flow launch would run (9 to 237 cameras), 2048 = dp = X y and the camera update as their own launch (ba_inv_apply) behind the data-flow launch, 4096 = its tasks dealt by workgroup index instead of taken by ticket (A/B only: needs every workgroup of the launch resident): results unchanged; (environment: SFM_FLOW_SOLVE=0 does the same for every handle of the process), 8192 = test of the data-flow launch's bounded waits: one hand-over is never announced, every wait gives up after 20 000 polls and the solve reports SFM_E_HIP) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 1024 = the column steps of the reduced solve as separate launches (ba_chol_step) where the single data-flow launch would run (9 to 237 cameras), 2048 = dp = X y and the camera update as their own launch (ba_inv_apply) behind the data-flow launch, 4096 = its tasks dealt by workgroup index instead of taken by ticket (A/B only: needs every workgroup of the launch resident): results unchanged; the environment variable SFM_FLOW_SOLVE=0 selects the column-step launches (bit 1024) for every handle of the process; 8192 = test of the data-flow launch's bounded waits: one hand-over is never announced, every wait gives up after 20 000 polls and the solve reports SFM_E_HIP) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
