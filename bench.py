@@ -91,13 +91,15 @@ def algorithmic_costs(n_cams, pt_ptr, n_obs):
     }
 
 
-def steady_state_launches(n_cams, schur_kernel, fused, debug=0):
+def steady_state_launches(n_cams, schur_kernel, fused, debug=0, reduce_in_solve=False):
     """Kernels ONE steady-state iteration launches and how often (what `hbm.measured_bytes_per_iteration` may sum):
     one-time kernels (ba_structure, ba_cam_major_*, ba_cam_prep) and the stand-alone ba_backsub of a fused iteration
     are not among them."""
     p = 7 * n_cams
     nbk = (p + 31) // 32
-    launches = {"ba_linearize": 1, schur_kernel: 1, "ba_schur_reduce": 1}
+    launches = {"ba_linearize": 1, schur_kernel: 1}
+    if not reduce_in_solve:      # (sfm_ba_iterate on one GPU leaves the dense product's split-K reduce to the data-flow launch: SFM_INFO_REDUCE_IN_SOLVE)
+        launches["ba_schur_reduce"] = 1
     if schur_kernel == "ba_schur_rows":
         launches["ba_schur_rows_reduce"] = 1
     if not fused:
@@ -528,7 +530,9 @@ def ba_measure(args, ctx, sfm, strong, full, collective):
             traffic_rec = json.load(open(tfile)).get(workload_key)
         except Exception:
             traffic_rec = None
-    launches = steady_state_launches(scene.n_cams, schur_kernel, fused=scene.n_cams <= 102 and not (args.debug & 16), debug=args.debug)
+    launches = steady_state_launches(scene.n_cams, schur_kernel, fused=scene.n_cams <= 102 and not (args.debug & 16), debug=args.debug,
+                                     reduce_in_solve=bool(engine.prob.info(native.INFO_REDUCE_IN_SOLVE)))
+    out["config"]["reduce_in_solve_launch"] = bool(engine.prob.info(native.INFO_REDUCE_IN_SOLVE))
     if traffic_rec:
         kernels = {"solve": ("ba_chol_flow", "ba_chol_step", "ba_inv_apply", "ba_back_solve", "ba_back_update", "ba_small_solve"), "schur": (schur_kernel,),
                    "reduce": ("ba_schur_reduce", "ba_schur_rows_reduce")}.get(dominant, ("ba_" + dominant,))

@@ -67,7 +67,7 @@ extern "C" {
                               * contribution (many cameras at low visibility: BASELINE config 4) */
 
 #define SFM_OPT_SCHUR        1
-#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 1024 = the column steps of the reduced solve as separate launches (ba_chol_step) where the single data-flow launch would run (9 to 237 cameras), 2048 = dp = X y and the camera update as their own launch (ba_inv_apply) behind the data-flow launch, 4096 = its tasks dealt by workgroup index instead of taken by ticket (A/B only: needs every workgroup of the launch resident): results unchanged; the environment variable SFM_FLOW_SOLVE=0 selects the column-step launches (bit 1024) for every handle of the process; 8192 = test of the data-flow launch's bounded waits: one hand-over is never announced, every wait gives up after 20 000 polls and the solve reports SFM_E_HIP) */
+#define SFM_OPT_DEBUG        3  /* profiling ablations of the Schur kernel (1 no MFMA, 4 no staging DMA: results are wrong when set; 8 = record clock stamps; 16 = keep ba_backsub and ba_linearize as separate launches, 64 = block column steps even for P <= 56 (no single-launch small-system solve), 256 = single-launch solve up to P = 64 instead of 56, 512 = block-row back substitution instead of dp = L^-T y with the inverse carried through the column steps, 128 = never pick the row-panel sparse product, 1024 = the column steps of the reduced solve as separate launches (ba_chol_step) where the single data-flow launch would run (9 to 237 cameras), 2048 = dp = X y and the camera update as their own launch (ba_inv_apply) behind the data-flow launch, 4096 = its tasks dealt by workgroup index instead of taken by ticket (A/B only: needs every workgroup of the launch resident): results unchanged; the environment variable SFM_FLOW_SOLVE=0 selects the column-step launches (bit 1024) for every handle of the process; 8192 = test of the data-flow launch's bounded waits: one hand-over is never announced, every wait gives up after 20 000 polls and the solve reports SFM_E_HIP; 16384 = the split-K reduce of the dense product always as its own launch (sfm_ba_iterate on one GPU otherwise leaves it to the first tasks of the data-flow launch: same sums in a fixed order) */
 #define SFM_OPT_DETERMINISTIC 4 /* 1: fixed summation order everywhere -- one wave per ba_linearize workgroup (ordered LDS accumulation), the
                                  * atomic-free dense Schur product, a single-writer split-K / camera-accumulator reduce.  Two runs from the
                                  * same state then agree bit for bit (the default path agrees to ~1e-13).  Needs the dense product to fit
@@ -93,6 +93,8 @@ extern "C" {
 #define SFM_INFO_N_OBS         5
 #define SFM_INFO_MAX_TRACK     6  /* longest track (observations of one point) */
 #define SFM_INFO_GRAPH_REPLAYS 7  /* iterations sfm_ba_iterate carried out as hipGraph replays (SFM_OPT_GRAPH) */
+#define SFM_INFO_REDUCE_IN_SOLVE 8 /* 1 if the last iteration sfm_ba_iterate enqueued left the split-K reduce of the dense product to the
+                                   * data-flow solve's launch (no ba_schur_reduce launch: one GPU, 37 to 237 cameras, not deterministic), else 0 */
 
 /* ---- kernel ids for sfm_ba_kernel_time ------------------------------------------------------- */
 #define SFM_K_PREP       0
@@ -340,6 +342,9 @@ int sfm_ba_debug_stamps(sfm_ba_problem* p, unsigned long long* out, int n);
  * block of a row + its two hand-over blocks, 2 = the hand-over block (i, i-1), 3 = a block of the rhs row, 4 = a block of an
  * identity row.  Returns the number of tasks (0 outside 2 .. 52 block columns); fills at most `capacity` of them. */
 int sfm_ba_flow_tasks(int nbk, int* out, int capacity);
+/* The same for n_cams cameras with the reduce deferred into the launch (sfm_ba_iterate on one GPU, dense product): type 5 = the
+ * accumulators of camera `row`, part `column` of 4; type 6 = block (row, column) of S, rows 8 q .. 8 q + 7 with q = key & 3. */
+int sfm_ba_flow_tasks_deferred(int n_cams, int* out, int capacity);
 
 /* Multi-GPU split of one iteration (points sharded by rank, cameras replicated):
  *   sfm_ba_linearize_reduce : this rank's partial reduced system [S (P x P, P = 7V padded to

@@ -116,6 +116,74 @@ __device__ __forceinline__ void cam_reduce_slice(const BaDev& d, int nrows, int 
   }
 }
 
+// Work split of both products.  Tiles are the lower-triangular pairs of blocks (128 rows of S in the dense product, 18
+// whole cameras in the sparse one), in four classes with
+// their own chunking: off-diagonal tiles (ti > tj, row-major order) whose row block is full, off-diagonal tiles
+// of the LAST block (which may be partly empty: its empty 16-row MFMA strips are skipped), full
+// diagonal tiles and the last diagonal tile.  A dense off-diagonal tile issues 2 x (strips of its row block)
+// MFMAs per SIMD and k-step (16 when full), a diagonal one the larger half of its lower sub-tiles (9 when full);
+// rows per chunk are inversely proportional, so every workgroup carries the same MFMA load.  Workgroup w's
+// partial tile goes to slab w; workgroups are numbered class by class, tile by tile, chunk by chunk.
+struct SchurPlan {
+  int nblk, n_off;
+  int chunks[4], rpc[4];        // per class (0 off full, 1 off last row, 2 diag full, 3 diag last): chunks per tile,
+                                // rows of Zd (dense) or points (sparse) per chunk
+  int ra_last;                  // 16-row strips of the last block that hold cameras (1..8)
+  int cam_blocks;               // 1: blocks of 18 whole cameras, block row r = camera 18 b + r / 7 (sparse tiles);
+                                // 0: blocks of 128 consecutive rows of S, block row r = row 128 b + r (dense product)
+  int dbg;                      // profiling ablations (SFM_OPT_DEBUG): 1 = no MFMA, 4 = no staging loads
+};
+
+struct SchurTileRef { int ti, tj, cls, first, chunk; };
+
+__host__ __device__ inline int plan_tiles_in_class(const SchurPlan& pl, int cls) {
+  const int last_row = pl.nblk - 1;                       // off-diagonal tiles with ti == nblk - 1
+  return cls == 0 ? pl.n_off - last_row : (cls == 1 ? last_row : (cls == 2 ? pl.nblk - 1 : 1));
+}
+__host__ __device__ inline int plan_wgs(const SchurPlan& pl) {
+  int w = 0;
+  for (int c = 0; c < 4; ++c) w += plan_tiles_in_class(pl, c) * pl.chunks[c];
+  return w;
+}
+// tile index (off-diagonal tiles first in row-major (ti, tj) order, then the diagonal ones) -> blocks, class,
+// first workgroup
+__host__ __device__ inline SchurTileRef plan_tile(const SchurPlan& pl, int tile) {
+  SchurTileRef r;
+  r.chunk = 0;
+  const int n0 = plan_tiles_in_class(pl, 0), n1 = plan_tiles_in_class(pl, 1), n2 = plan_tiles_in_class(pl, 2);
+  if (tile < pl.n_off) {
+    int t = tile;
+    r.ti = 1;
+    while (t >= r.ti) { t -= r.ti; ++r.ti; }
+    r.tj = t;
+    if (tile < n0) { r.cls = 0; r.first = tile * pl.chunks[0]; }
+    else { r.cls = 1; r.first = n0 * pl.chunks[0] + (tile - n0) * pl.chunks[1]; }
+  } else {
+    r.ti = r.tj = tile - pl.n_off;
+    const int base = n0 * pl.chunks[0] + n1 * pl.chunks[1];
+    if (r.ti < n2) { r.cls = 2; r.first = base + r.ti * pl.chunks[2]; }
+    else { r.cls = 3; r.first = base + n2 * pl.chunks[2]; }
+  }
+  return r;
+}
+// workgroup -> tile and chunk
+__host__ __device__ inline SchurTileRef plan_locate(const SchurPlan& pl, int w) {
+  int tile0 = 0, w0 = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int nt = plan_tiles_in_class(pl, c), span = nt * pl.chunks[c];
+    if (w < w0 + span || c == 3) {
+      const int t = (w - w0) / pl.chunks[c];
+      // classes are stored off-full, off-last, diag-full, diag-last = exactly the tile index order
+      SchurTileRef r = plan_tile(pl, tile0 + t);
+      r.chunk = (w - w0) - t * pl.chunks[c];
+      return r;
+    }
+    w0 += span;
+    tile0 += nt;
+  }
+  return SchurTileRef{0, 0, 0, 0, 0};
+}
+
 struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   int used = 0;
@@ -151,6 +219,11 @@ struct sfm_ba_problem {
   sfm_comm* comm = nullptr;  // library-owned RCCL communicator (sfm_ba_set_comm): the iterations all-reduce [S | rhs] themselves
   // Schur-product plan (sfm_ba_schur.hip)
   void* schur_ws = nullptr;      // [chunks][tiles][128][128] split-K partial tiles
+  const void* flow_tasks_red = nullptr;  // task table of the data-flow solve with the reduce deferred into it (sfm_ba_solve.hip)
+  int flow_ntasks_red = 0;
+  double* flow_camsum = nullptr; // [4][35 V] partial camera sums of the deferred reduce
+  bool last_reduce_deferred = false;   // what the last ba_enqueue_schur decided (SFM_INFO_REDUCE_IN_SOLVE; survives the solve and graph replays)
+  bool reduce_deferred = false;  // the last ba_enqueue_schur left its slabs unsummed: the next solve is the data-flow launch with FlowRed
   int* schur_blk_ptr = nullptr;  // [N][nblk + 1] first observation of a point in each 18-camera block (sparse path)
   bool schur_mfma_ok = false;
   // row-panel sparse product (sfm_ba_schur_rows.hip): camera-major observation list and work split, built on first use
@@ -183,12 +256,14 @@ int ba_rows_plan(sfm_ba_problem* p);
 int ba_rows_enqueue(sfm_ba_problem* p, hipStream_t s);
 int ba_enqueue_structure(sfm_ba_problem* p);      // validate the CSR, fill obs_pt / per-point block offsets / longest track (device)
 int ba_schur_prepare_dense(sfm_ba_problem* p, hipStream_t s);
-int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s);
+int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s, bool allow_defer);
+SchurPlan ba_schur_dense_plan(const sfm_ba_problem* p);
+bool ba_solve_can_defer_reduce(const sfm_ba_problem* p);      // sfm_ba_solve.hip
 void ba_tick(sfm_ba_problem* p, int kernel_class, bool begin, hipStream_t s);   // hipEvent bracket of a kernel class (SFM_OPT_TIMING)
 bool ba_schur_uses_mfma(const sfm_ba_problem* p);
 int ba_schur_choice(const sfm_ba_problem* p);
 int ba_enqueue_prep(sfm_ba_problem* p);
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks);
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool allow_defer = false);
 int ba_enqueue_solve_update(sfm_ba_problem* p, double lambda, int quirks);
 int ba_flush(sfm_ba_problem* p);      // complete a deferred back substitution
 void ba_graph_drop(sfm_ba_problem* p); // forget the captured iteration bodies

@@ -487,7 +487,7 @@ int ba_flush(sfm_ba_problem* p) {
   return enqueue_backsub(p, p->pending_lambda, p->pending_quirks);
 }
 
-int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
+int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks, bool allow_defer) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   bool fused = p->backsub_pending && ba_can_fuse(p) && lambda == p->pending_lambda && quirks == p->pending_quirks;
@@ -531,7 +531,7 @@ int ba_enqueue_linearize_reduce(sfm_ba_problem* p, double lambda, int quirks) {
   p->lin_grid = grid;
   ba_tick(p, SFM_K_LINEARIZE, false, s);
   SFM_HIP(hipGetLastError());
-  SFM_TRY(ba_enqueue_schur(p, s));
+  SFM_TRY(ba_enqueue_schur(p, s, allow_defer));
   return SFM_OK;
 }
 
@@ -565,7 +565,7 @@ static int capture_body(sfm_ba_problem* p, double lambda, int quirks) {
   hipStream_t s = p->stream;
   const int slot = p->cur;
   SFM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-  int st = ba_enqueue_linearize_reduce(p, lambda, quirks);
+  int st = ba_enqueue_linearize_reduce(p, lambda, quirks, true);      // graphs are used without a communicator only
   if (st == SFM_OK) st = ba_enqueue_solve_update(p, lambda, quirks);
   hipGraph_t graph = nullptr;
   const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -603,7 +603,7 @@ int ba_enqueue_iterations(sfm_ba_problem* p, double lambda, int iters, int quirk
       }
       continue;
     }
-    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks));
+    SFM_TRY(ba_enqueue_linearize_reduce(p, lambda, quirks, p->comm == nullptr));      // nothing but the solve reads S: its reduce may ride in the solve's launch
     // sharded loop inside the library: this rank's partial [S | rhs] -> the sum over all ranks, on the problem's stream
     if (p->comm) SFM_TRY(comm_all_reduce_f64(p->comm, p->dev.red, red_size(p->dev.nbk), p->stream));
     SFM_TRY(ba_enqueue_solve_update(p, lambda, quirks));

@@ -44,11 +44,27 @@ __host__ __device__ inline int flow_fx(int nbk, int e, int m) { return kFlowHdr 
 __host__ __device__ inline int flow_fw(int nbk, int k) { return kFlowHdr + 2 * nbk * nbk + k; }                       // W_k published
 __host__ __device__ inline int flow_fy(int nbk, int k) { return kFlowHdr + 2 * nbk * nbk + nbk + k; }                 // y_k published
 __host__ __device__ inline int flow_fh(int nbk, int i, int t) { return kFlowHdr + 2 * nbk * nbk + 2 * nbk + 3 * i + t; }   // hand-over block (i, i-2+t)
-__host__ __device__ inline int flow_words(int nbk) { return kFlowHdr + 2 * nbk * nbk + 5 * nbk; }
+__host__ __device__ inline int flow_words_solve(int nbk) { return kFlowHdr + 2 * nbk * nbk + 5 * nbk; }
+// deferred reduce (S summed from the product's split-K slabs inside this launch): camera c's accumulators, part 0..3; quarter q of block (i, k) of S
+__host__ __device__ inline int flow_fc(int nbk, int c, int part) { return flow_words_solve(nbk) + 4 * c + part; }
+__host__ __device__ inline int flow_fs(int nbk, int i, int k, int q) { return flow_words_solve(nbk) + 4 * (5 * nbk + 1) + 4 * (i * (i + 1) / 2 + k) + q; }
+__host__ __device__ inline int flow_fcost(int nbk) { return flow_fs(nbk, nbk, 0, 0); }      // this linearisation's cost is stored
+__host__ __device__ inline int flow_words(int nbk) { return flow_fcost(nbk) + 1; }
 
 // task table (host-built once per problem, sorted by the column a task waits for last)
-enum { FLOW_T1 = 0, FLOW_CLOSER = 1, FLOW_H1 = 2, FLOW_RHS = 3, FLOW_IDENT = 4 };
-struct FlowTask { int type, i, k, key; };
+enum { FLOW_T1 = 0, FLOW_CLOSER = 1, FLOW_H1 = 2, FLOW_RHS = 3, FLOW_IDENT = 4, FLOW_CAMSUM = 5, FLOW_SRED = 6, FLOW_COST = 7 };
+struct FlowTask { int type, i, k, key; };      // CAMSUM: i = camera, k = part;  SRED: block (i, k), quarter key & 3 (after sorting)
+
+// Deferred reduce (sfm_ba_iterate on one GPU, dense product): ba_schur_reduce is not launched; the first tasks of this launch sum
+// ba_linearize's per-workgroup camera accumulators (CAMSUM: one camera, a quarter of the rows) and the product's split-K slabs
+// (SRED: 8 rows of a 32x32 block of S, + the camera sums on the camera-diagonal, fixed order: deterministic), block column by
+// block column, and the chain starts as soon as D_0 is there instead of behind the whole reduce and a launch boundary.
+struct FlowRed {
+  const double* ws;      // the product's slabs (null: S and rhs are in `red` already)
+  double* camsum;        // [4][35 V] partial sums of lin_ws
+  SchurPlan plan;
+  int lin_rows, lin_grid;
+};
 
 // LDS carve (doubles)
 constexpr int FS_DM = 0;                  // [32][33] D_j, row-major (elimination: lane = row)
@@ -206,7 +222,119 @@ struct FlowCtx {
   int lane, lr, lk, gw, sx, sy;
   FlowWait w;
   unsigned long long* stamps;      // SFM_OPT_DEBUG bit 8 (thread 0 of a task workgroup), else null
+  bool sred;                       // S comes from SRED tasks of this launch (wait for them, sc1 loads), rhs from the camera sums
+  const double* camsum; int ncam35;
 };
+
+// Blocks (i, k0 .. k1) of S are there (deferred reduce: the 4 (k1 - k0 + 1) quarter flags are neighbours -- one poll loop, so that
+// the loads of all of them travel together afterwards)
+__device__ __forceinline__ void flow_wait_S(FlowCtx& c, int i, int k0, int k1) {
+  if (!c.sred) return;
+  for (int n = 4 * (k1 - k0 + 1), f = flow_fs(c.nbk, i, k0, 0); n > 0; n -= 16, f += 16) (void)c.w.wait_terms(f, 0, 0, 1, min(16, n), min(16, n));
+}
+// tile (sx, sy) of S_blk^T of block (i, k): as the reduce kernel left it (plain loads), or as this launch's SRED tasks published it
+__device__ __forceinline__ f64x4 flow_ld_S(const FlowCtx& c, int i, int k, int sx, int sy) {
+  const double* p = c.redp + red_blk_base(i, k) + (16 * sy + c.lr) * kNB + 16 * sx + c.lk;
+  if (!c.sred) return f64x4{p[0], p[4], p[8], p[12]};
+  f64x4 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) v[g] = __hip_atomic_load(p + 4 * g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+// every part of the camera sums of cameras c0 .. c1 is there
+__device__ __forceinline__ void flow_wait_cams(FlowCtx& c, int c0, int c1) {
+  for (int n = 4 * (c1 - c0 + 1), f = flow_fc(c.nbk, c0, 0); n > 0; n -= 16, f += 16) (void)c.w.wait_terms(f, 0, 0, 1, min(16, n), min(16, n));
+}
+__device__ __forceinline__ double flow_camsum(const FlowCtx& c, int t) {      // element t of [V][35], parts added in order
+  double u = 0;
+#pragma unroll
+  for (int part = 0; part < 4; ++part) u += __hip_atomic_load(c.camsum + (size_t)part * c.ncam35 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return u;
+}
+
+// CAMSUM: rows [part/4, (part+1)/4) of lin_ws for the 35 accumulators of one camera (thread = accumulator e, row residue g mod 7)
+__device__ __forceinline__ void flow_task_camsum(FlowCtx& c, const BaDev& d, const FlowRed& fr, int cam, int part) {
+  const int tid = threadIdx.x, T = 35 * d.V, per = (fr.lin_rows + 3) / 4, r0 = part * per, r1 = min(fr.lin_rows, r0 + per);
+  double* sums = c.sm + FS_B;      // [7][35]
+  unsigned long long* stamp = (c.stamps && cam == 0 && part == 0) ? c.stamps + 128 : nullptr;      // 100 MHz clock: [0] start, [1] rows summed, [2] published
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  if (tid < 245) {
+    const int e = tid % 35, g = tid / 35;
+    const double* src = d.lin_ws + (size_t)cam * 35 + e;
+    double s = 0;
+    for (int rb = r0 + g; rb < r1; rb += 7 * 28) {      // 28 loads in flight (all of a part at 768 rows), added in row order
+      double v[28];
+#pragma unroll
+      for (int u = 0; u < 28; ++u) v[u] = rb + 7 * u < r1 ? src[(size_t)(rb + 7 * u) * T] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 28; ++u) s += v[u];
+    }
+    sums[tid] = s;
+  }
+  __syncthreads();
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  if (tid < 35) {
+    double t = 0;
+#pragma unroll
+    for (int g = 0; g < 7; ++g) t += sums[35 * g + tid];
+    __hip_atomic_store(fr.camsum + (size_t)part * T + cam * 35 + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  flow_drain();
+  __syncthreads();
+  if (tid == 0) flow_publish(c.flow, flow_fc(c.nbk, cam, part), c.epoch);
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
+}
+
+// COST: the cost of this linearisation (what ba_schur_reduce's last block does); the workgroup that advances iter_count at the end of
+// the solve waits for it
+__device__ __forceinline__ void flow_task_cost(FlowCtx& c, const BaDev& d, const FlowRed& fr) {
+  if (threadIdx.x < 64) {
+    double s = 0;
+    for (int r = c.lane; r < fr.lin_grid; r += 64) s += d.cost_ws[r];
+    s = wave_sum(s);
+    if (c.lane == 0) d.cost[min(*d.iter_count, kStatSlots - 1)] = s;
+  }
+  flow_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) flow_publish(c.flow, flow_fcost(c.nbk), c.epoch);
+}
+
+// SRED: rows 8q .. 8q+7 of block (i, k) of S = camera sums (on a camera's own 7x7 block) - the tile's slabs in chunk order;
+// zero above the diagonal and on the padding (what the reduce kernel leaves of a cleared `red`)
+__device__ __forceinline__ void flow_task_sred(FlowCtx& c, const BaDev& d, const FlowRed& fr, int i, int k, int q) {
+  const int tid = threadIdx.x, r = tid >> 5, cc = tid & 31, row = kNB * i + 8 * q + r, col = kNB * k + cc;
+  const int ti = row / kSchurRB, tj = col / kSchurRB;
+  const SchurTileRef tr = plan_tile(fr.plan, ti > tj ? ti * (ti - 1) / 2 + tj : fr.plan.n_off + ti);
+  const int chunks = fr.plan.chunks[tr.cls];
+  unsigned long long* stamp = (c.stamps && i == 1 && k == 0 && q == 0) ? c.stamps + 136 : nullptr;      // [0] start, [1] slabs summed, [2] camera sums seen, [3] published
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  const double* src = fr.ws + (size_t)tr.first * (kSchurRB * kSchurRB) + (row % kSchurRB) * kSchurRB + (col % kSchurRB);
+  double s = 0;
+  for (int cb = 0; cb < chunks; cb += 40) {      // 40 loads in flight (a diagonal tile's 37 slabs at C3 in one trip), added in chunk order
+    double v[40];
+#pragma unroll
+    for (int u = 0; u < 40; ++u) v[u] = cb + u < chunks ? src[(size_t)(cb + u) * (kSchurRB * kSchurRB)] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 40; ++u) s += v[u];
+  }
+  double v = -s;
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  if (k >= i - 1) {
+    const int c0 = (kNB * i + 8 * q) / 7, c1 = min(d.V - 1, (kNB * i + 8 * q + 7) / 7);
+    if (c0 <= c1) flow_wait_cams(c, c0, c1);
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
+    if (row < d.P && col <= row && row / 7 == col / 7) {
+      const int ii = row % 7, jj = col % 7;
+      v += flow_camsum(c, (row / 7) * 35 + ii * (ii + 1) / 2 + jj);
+    }
+  }
+  if (row >= d.P || col > row) v = 0;
+  __hip_atomic_store(c.redp + red_blk_base(i, k) + (8 * q + r) * kNB + cc, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  flow_drain();
+  __syncthreads();
+  if (tid == 0) flow_publish(c.flow, flow_fs(c.nbk, i, k, q), c.epoch);
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Tasks (four waves, wave (sx, sy) owns accumulator tile (sx, sy)).
@@ -272,7 +400,8 @@ __device__ __forceinline__ void flow_finish(FlowCtx& c, const f64x4& t, int own,
 __device__ __forceinline__ void flow_task_t1(FlowCtx& c, int i, int k) {
   unsigned long long* stamp = (c.stamps && k == i - 4) ? c.stamps + 128 + 8 * i : nullptr;      // the block the closer of row i waits for last
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
-  const f64x4 s = ctile_ld_S(c.redp + red_blk_base(i, k), c.sx, c.sy, c.lr, c.lk);
+  flow_wait_S(c, i, k, k);
+  const f64x4 s = flow_ld_S(c, i, k, c.sx, c.sy);
   f64x4 acc = {0, 0, 0, 0};
   flow_row_sum<0>(c, acc, k, i, 0, k);
   if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
@@ -283,7 +412,8 @@ __device__ __forceinline__ void flow_task_t1(FlowCtx& c, int i, int k) {
 // hand-over block (i, i-1) through column i-4
 __device__ __forceinline__ void flow_task_h1(FlowCtx& c, int i) {
   const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk);
-  const f64x4 s = ctile_ld_S(c.redp + red_blk_base(i, i - 1), c.sx, c.sy, c.lr, c.lk);
+  flow_wait_S(c, i, i - 1, i - 1);
+  const f64x4 s = flow_ld_S(c, i, i - 1, c.sx, c.sy);
   f64x4 acc = {0, 0, 0, 0};
   flow_row_sum<0>(c, acc, i - 1, i, 0, i - 3);
   __syncthreads();      // every wave has its part of S before any wave overwrites the block
@@ -297,9 +427,10 @@ __device__ __forceinline__ void flow_task_h1(FlowCtx& c, int i) {
 // tiles of row i and are complete before W_i-3 exists; what W_i-3 releases is one product, an LDS round trip and two terms.
 __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   const int coff = ctile_off(c.sx, c.sy, c.lr, c.lk), k = i - 3, nbk = c.nbk;
-  const f64x4 sT = ctile_ld_S(c.redp + red_blk_base(i, k), c.sx, c.sy, c.lr, c.lk);
-  const f64x4 s0 = ctile_ld_S(c.redp + red_blk_base(i, i - 2), c.sx, c.sy, c.lr, c.lk);
-  const f64x4 s2 = ctile_ld_S(c.redp + red_blk_base(i, i), c.sx, c.sy, c.lr, c.lk);
+  flow_wait_S(c, i, k, i);
+  const f64x4 sT = flow_ld_S(c, i, k, c.sx, c.sy);
+  const f64x4 s0 = flow_ld_S(c, i, i - 2, c.sx, c.sy);
+  const f64x4 s2 = flow_ld_S(c, i, i, c.sx, c.sy);
   f64x4 accT = {0, 0, 0, 0}, acc0 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
   unsigned long long* stamp = c.stamps ? c.stamps + 640 + 8 * i : nullptr;      // 100 MHz clock (s_memrealtime): comparable across workgroups
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -378,11 +509,16 @@ __device__ __forceinline__ void flow_task_closer(FlowCtx& c, int i) {
   if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
 }
 
-__device__ __forceinline__ void flow_task_rhs(FlowCtx& c, int k) {
+__device__ __forceinline__ void flow_task_rhs(FlowCtx& c, int k, int P) {
   f64x4 s = {0, 0, 0, 0};
+  if (c.sred) flow_wait_cams(c, (kNB * k) / 7, min(P - 1, kNB * k + kNB - 1) / 7);
   if (c.sy == 0 && c.lr == 0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) s[g] = c.rhs[k * kNB + 16 * c.sx + c.lk + 4 * g];
+    for (int g = 0; g < 4; ++g) {
+      const int row = k * kNB + 16 * c.sx + c.lk + 4 * g;
+      if (!c.sred) s[g] = c.rhs[row];
+      else if (row < P) s[g] = flow_camsum(c, (row / 7) * 35 + 28 + row % 7);
+    }
   }
   f64x4 acc = {0, 0, 0, 0};
   flow_row_sum<1>(c, acc, k, 0, 0, k);
@@ -447,6 +583,7 @@ __device__ __forceinline__ void flow_task_dp(FlowCtx& c, const BaDev& d, int e, 
   __syncthreads();
   if (!*is_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (c.sred) c.w.wait(flow_fcost(nbk));      // (this linearisation's has been stored)
   if (tid == 0) *d.iter_count += 1;      // the next linearisation's cost goes to the next slot (sfm_ba_get_stats)
   for (int v = tid; v < d.V; v += 256) {
     double cam[7];
@@ -476,7 +613,7 @@ __device__ __forceinline__ void flow_lds_post(int* word, int value) {      // af
   if ((threadIdx.x & 255) == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double lambda) {
+__device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double lambda, const FlowRed& fr) {
   const int nbk = c.nbk, P = d.P;
   const int tid = threadIdx.x, lane = c.lane, grp = tid >> 8;
   const int sx = c.sx, sy = c.sy, lr = c.lr, lk = c.lk, gw = c.gw;
@@ -518,7 +655,38 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
   for (int t = 0; t < 3; ++t) { pf[t][0] = f64x2{0, 0}; pf[t][1] = f64x2{0, 0}; }
 #pragma unroll
   for (int t = 0; t < 8; ++t) pfb[t] = 0;
-  if (grp == 0) { __builtin_amdgcn_s_setprio(3); put_d(0, ctile_ld_S(c.redp + red_blk_base(0, 0), sx, sy, lr, lk)); }
+  if (c.sred) {
+    // Deferred reduce: D_0 is summed here, by all eight waves, straight into LDS -- no task, no flag, no second trip through memory
+    // between the slabs and the first elimination.  Thread = (row, column pair): one 16-byte load per slab, all of them in flight.
+    const int row = tid >> 4, cp = 2 * (tid & 15);
+    const SchurTileRef tr = plan_tile(fr.plan, fr.plan.n_off);
+    const int chunks = fr.plan.chunks[tr.cls];
+    const double* src = fr.ws + (size_t)tr.first * (kSchurRB * kSchurRB) + row * kSchurRB + cp;
+    f64x2 s = {0, 0};
+    for (int cb = 0; cb < chunks; cb += 40) {
+      f64x2 v[40];
+#pragma unroll
+      for (int u = 0; u < 40; ++u) v[u] = (cb + u < chunks && cp <= row) ? *reinterpret_cast<const f64x2*>(src + (size_t)(cb + u) * (kSchurRB * kSchurRB)) : f64x2{0, 0};
+#pragma unroll
+      for (int u = 0; u < 40; ++u) s += v[u];
+    }
+    if (stamp && tid == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+    flow_wait_cams(c, 0, min(d.V - 1, (kNB - 1) / 7));
+    if (stamp && tid == 0) stamp[13] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = cp + h;
+      double t = 0;
+      if (row < P && col <= row) {
+        t = -s[h];
+        if (row / 7 == col / 7) { const int ii = row % 7, jj = col % 7; t += flow_camsum(c, (row / 7) * 35 + ii * (ii + 1) / 2 + jj); }
+      }
+      if (row == col) t = row < P ? t + lambda : 1.0;
+      Dm[row][col] = t;
+    }
+    if (stamp && tid == 0) stamp[14] = __builtin_amdgcn_s_memrealtime();
+    if (grp == 0) __builtin_amdgcn_s_setprio(3);
+  } else if (grp == 0) { __builtin_amdgcn_s_setprio(3); put_d(0, flow_ld_S(c, 0, 0, sx, sy)); }
   if (tid == 0) { eflag[0] = 0; pctr[0] = 0; ectr[0] = 0; la_ready[0] = 0; c2_done[0] = 0; }
   __syncthreads();
 
@@ -569,9 +737,10 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
 #pragma unroll
           for (int h = 0; h < 2; ++h) *reinterpret_cast<f64x2*>(B0 + t * kBlk + 2 * (u0 + 256 * h)) = pf[t][h];
       } else {
-        if (r == 2) ctile_st_lds(B0, coff, ctile_ld_S(c.redp + red_blk_base(2, 0), sx, sy, lr, lk));
-        ctile_st_lds(B1, coff, ctile_ld_S(c.redp + red_blk_base(r, r - 1), sx, sy, lr, lk));
-        ctile_st_lds(B2, coff, ctile_ld_S(c.redp + red_blk_base(r, r), sx, sy, lr, lk));
+        flow_wait_S(c, r, 0, r);
+        if (r == 2) ctile_st_lds(B0, coff, flow_ld_S(c, 2, 0, sx, sy));
+        ctile_st_lds(B1, coff, flow_ld_S(c, r, r - 1, sx, sy));
+        ctile_st_lds(B2, coff, flow_ld_S(c, r, r, sx, sy));
       }
       pf_ok = false;
       if (stamp) { stamp[256 + 8 * j + 0] = __builtin_amdgcn_s_memtime(); stamp[384 + 8 * j + 2] = __builtin_amdgcn_s_memrealtime(); }
@@ -686,10 +855,9 @@ __device__ __forceinline__ void flow_chain(FlowCtx& c, const BaDev& d, double la
 
 // Workgroup 0 is the chain; the others take the tasks of the table one after the other (sorted by column: a task waits only for
 // tasks before it).
-__global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda, int cur) {
+__global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* flow, const FlowTask* tasks, int ntasks, double lambda, int cur, FlowRed fr) {
   extern __shared__ __attribute__((aligned(16))) double flow_sm[];
   const int tid = threadIdx.x;
-  if (blockIdx.x != 0 && tid >= 256) return;      // tasks are run by four waves
   FlowCtx c;
   c.red = flow_buf(d.red); c.xinv = flow_buf(d.xinv); c.ldiag = flow_buf(d.ldiag);
   c.redp = d.red; c.rhs = d.red + red_rhs_off(d.nbk);
@@ -700,27 +868,39 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   c.gw = (tid >> 6) & 3; c.sx = c.gw >> 1; c.sy = c.gw & 1;
   c.w = FlowWait{flow, c.epoch, d.status, false, (d.debug & 8192) ? 20000u : kFlowSpinLimit};
   c.stamps = (d.stamps && tid == 0 && d.nbk <= 16) ? d.stamps : nullptr;      // the 1024 stamp slots are laid out for up to 16 block columns
-  if (blockIdx.x == 0) {
-    flow_chain(c, d, lambda);
+  c.sred = fr.ws != nullptr; c.camsum = fr.camsum; c.ncam35 = 35 * d.V;
+  // Roles and tasks are TAKEN (one agent-scope ticket each), not dealt by workgroup index: the first workgroup to arrive is the chain
+  // (workgroups of a launch start over several microseconds, and not in index order), the others take the tasks in table order.  A
+  // task waits only for the chain and for tasks earlier in the table, and those have been taken by workgroups that are running -- so
+  // the launch makes progress with any number of resident workgroups (two problems on two streams, several ranks rehearsed on one
+  // GPU), not only when all of its workgroups hold a CU at the same time.
+  int* slot = c.smi + 20;
+  const bool dealt = (d.debug & 4096) != 0;      // SFM_OPT_DEBUG bit 4096 (A/B only): roles and tasks by workgroup index; needs every workgroup resident
+  if (tid == 0) *slot = dealt ? (int)blockIdx.x : (int)__hip_atomic_fetch_add(flow + kFlowTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int first = *slot;
+  if (first == 0) {
+    if (c.stamps) { c.stamps[5] = __builtin_amdgcn_s_memtime(); c.stamps[6] = __builtin_amdgcn_s_memrealtime(); }      // kernel entry: step 0 starts when D_0 is there
+    flow_chain(c, d, lambda, fr);
   } else {
-    // Tasks are TAKEN in table order (one agent-scope ticket per task), not dealt by workgroup index: a task waits only for tasks
-    // earlier in the table, and those have been taken by workgroups that are running -- so the launch makes progress with any
-    // number of resident workgroups (two problems on two streams, several ranks rehearsed on one GPU), not only when all of
-    // its workgroups hold a CU at the same time.
-    int* slot = c.smi + 20;
-    const bool dealt = (d.debug & 4096) != 0;      // SFM_OPT_DEBUG bit 4096 (A/B only): tasks dealt by workgroup index; needs every workgroup resident
+    if (tid >= 256) return;      // tasks are run by four waves
     for (int round = 0;; ++round) {
-      if (tid == 0) *slot = dealt ? (int)blockIdx.x - 1 + round * ((int)gridDim.x - 1) : (int)__hip_atomic_fetch_add(flow + kFlowTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int t = *slot;      // every task below passes a barrier before this word is written again
+      if (round > 0) {
+        if (tid == 0) *slot = dealt ? first + round * ((int)gridDim.x - 1) : (int)__hip_atomic_fetch_add(flow + kFlowTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+      const int t = *slot - 1;      // every task below passes a barrier before this word is written again
       if (t >= ntasks) break;
       const FlowTask tk = tasks[t];
       switch (tk.type) {
         case FLOW_T1: flow_task_t1(c, tk.i, tk.k); break;
         case FLOW_CLOSER: flow_task_closer(c, tk.i); break;
         case FLOW_H1: flow_task_h1(c, tk.i); break;
+        case FLOW_CAMSUM: flow_task_camsum(c, d, fr, tk.i, tk.k); break;
+        case FLOW_SRED: flow_task_sred(c, d, fr, tk.i, tk.k, tk.key & 3); break;
+        case FLOW_COST: flow_task_cost(c, d, fr); break;
         case FLOW_RHS:
-          flow_task_rhs(c, tk.k);
+          flow_task_rhs(c, tk.k, d.P);
           if (cur >= 0 && tk.k == d.nbk - 1) flow_task_dp(c, d, d.nbk - 1, cur);
           break;
         default:
@@ -743,18 +923,38 @@ __global__ __launch_bounds__(512) void ba_chol_flow_kernel(BaDev d, unsigned* fl
   }
 }
 
-// the task table of a problem with nbk block columns, in the order the workgroups take it
-inline std::vector<FlowTask> flow_build_tasks(int nbk) {
+// The task table of a problem with nbk block columns, in the order the workgroups take it.  Keys: 64 x (the last column a task waits
+// for) + its place among that column's tasks; a task waits only for the chain and for tasks before it in the table.
+// V > 0: the table of the deferred reduce (V cameras): CAMSUM and SRED tasks ahead of their readers -- block (i, k) of S is read by
+// the chain (i < 3), by the task of L[i][k] (k <= i-4), by the closer of row i (k = i-3, i-2, i) or by its hand-over task (k = i-1).
+inline std::vector<FlowTask> flow_build_tasks(int nbk, int V = 0) {
   std::vector<FlowTask> t;
-  for (int i = 3; i < nbk; ++i) {
-    t.push_back(FlowTask{FLOW_CLOSER, i, i - 3, 8 * (i - 3) + 0});
-    t.push_back(FlowTask{FLOW_H1, i, i - 1, 8 * std::max(0, i - 4) + 2});      // after the block (i, i-4) of the same column
-    for (int k = 0; k <= i - 4; ++k) t.push_back(FlowTask{FLOW_T1, i, k, 8 * k + 1});
+  if (V > 0) {
+    t.push_back(FlowTask{FLOW_COST, 0, 0, 9});      // behind the first block rows' sums
+    // ahead of everything: what the chain's first steps read, block row by block row (the camera sums of a row, then its blocks of S)
+    for (int c = 0; c < V; ++c) {
+      const int ic = (7 * c) / kNB;
+      for (int part = 0; part < 4; ++part) t.push_back(FlowTask{FLOW_CAMSUM, c, part, 64 * std::max(0, ic - 4) + (ic <= 4 ? 2 * ic : 0)});
+    }
+    for (int k = 0; k < nbk; ++k)
+      for (int i = std::max(k, 1); i < nbk; ++i)      // (block (0, 0) is summed by the chain itself)
+        for (int q = 0; q < 4; ++q) {
+          const int g = k <= i - 4 ? k : std::max(0, i - 4);
+          t.push_back(FlowTask{FLOW_SRED, i, k, 64 * g + (g == 0 ? 2 * std::min(i, 15) + 1 : 1)});
+        }
   }
-  for (int k = 0; k < nbk; ++k) t.push_back(FlowTask{FLOW_RHS, 0, k, 8 * k + 3});
+  for (int i = 3; i < nbk; ++i) {
+    t.push_back(FlowTask{FLOW_CLOSER, i, i - 3, 64 * (i - 3) + 40});
+    t.push_back(FlowTask{FLOW_H1, i, i - 1, 64 * std::max(0, i - 4) + 48});      // after the block (i, i-4) of the same column
+    for (int k = 0; k <= i - 4; ++k) t.push_back(FlowTask{FLOW_T1, i, k, 64 * k + 44});
+  }
+  for (int k = 0; k < nbk; ++k) t.push_back(FlowTask{FLOW_RHS, 0, k, 64 * k + 52});
   for (int e = 0; e + 1 < nbk; ++e)
-    for (int k = e + 1; k < nbk; ++k) t.push_back(FlowTask{FLOW_IDENT, e, k, 8 * k + 4});
+    for (int k = e + 1; k < nbk; ++k) t.push_back(FlowTask{FLOW_IDENT, e, k, 64 * k + 56});
   std::stable_sort(t.begin(), t.end(), [](const FlowTask& x, const FlowTask& y) { return x.key < y.key; });
+  int q = 0;
+  for (FlowTask& x : t)
+    if (x.type == FLOW_SRED) x.key = (x.key & ~3) | (q++ & 3);      // the four quarters of a block stay adjacent (stable sort): 0, 1, 2, 3
   return t;
 }
 

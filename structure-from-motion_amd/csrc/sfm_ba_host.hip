@@ -298,7 +298,7 @@ int sfm_ba_destroy(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   void* ptrs[] = {d.pt_ptr, d.cam_idx, d.obs_pt, d.u, d.v, d.cams, d.px, d.py, d.pz, d.prep[0], d.prep[1],
                   d.Z, d.Zd, d.lin_ws, d.stamps, p->own_red, d.delta, d.ldiag, d.xinv, d.sync_ctr, d.flow, d.status, d.sinfo, d.cost, d.cost_ws, d.iter_count,
-                  p->schur_ws, p->schur_blk_ptr, p->cam_ptr, p->cam_ent, p->cam_pairs, p->rows_table, p->rows_first, p->rows_ws};
+                  p->schur_ws, p->flow_camsum, p->schur_blk_ptr, p->cam_ptr, p->cam_ent, p->cam_pairs, p->rows_table, p->rows_first, p->rows_ws};
   for (void* q : ptrs) if (q) pool_free(q);
   for (auto& t : p->timers)
     for (auto& e : t.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -385,6 +385,7 @@ int sfm_ba_info(sfm_ba_problem* p, int what, int64_t* value) {
     case SFM_INFO_N_OBS: *value = p->dev.M; return SFM_OK;
     case SFM_INFO_MAX_TRACK: *value = p->max_track; return SFM_OK;
     case SFM_INFO_GRAPH_REPLAYS: *value = p->graph_replays; return SFM_OK;
+    case SFM_INFO_REDUCE_IN_SOLVE: *value = p->last_reduce_deferred ? 1 : 0; return SFM_OK;
     default: set_error("sfm_ba_info: unknown item %d", what); return SFM_E_SHAPE;
   }
 }

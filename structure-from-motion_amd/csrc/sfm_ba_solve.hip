@@ -758,32 +758,38 @@ __global__ __launch_bounds__(SM_THREADS) void ba_small_solve_kernel(BaDev d, int
 #include "sfm_ba_flow.h"
 namespace sfm {
 
+// One device copy of a task table per (device, key) for the life of the process, so that the per-view sfm_ba_append of the drop-in
+// classes (a new problem object every time) neither allocates nor copies it again.  key: nbk (S reduced by its own launch) or
+// 1000 + V (the deferred reduce: one CAMSUM task per camera and part).
+static int flow_task_table(int key, int nbk, int V, const void** table, int* ntasks) {
+  static std::mutex mu;
+  static std::map<long long, std::pair<void*, int>> tables;
+  std::lock_guard<std::mutex> lock(mu);
+  const long long k = (long long)ctx().device * 100000 + key;
+  auto it = tables.find(k);
+  if (it == tables.end()) {
+    const std::vector<FlowTask> tasks = flow_build_tasks(nbk, V);
+    void* tk = nullptr;
+    SFM_HIP(hipMalloc(&tk, sizeof(FlowTask) * std::max<size_t>(1, tasks.size())));
+    if (!tasks.empty()) SFM_HIP(hipMemcpy(tk, tasks.data(), sizeof(FlowTask) * tasks.size(), hipMemcpyHostToDevice));
+    it = tables.emplace(k, std::make_pair(tk, (int)tasks.size())).first;
+  }
+  *table = it->second.first;
+  *ntasks = it->second.second;
+  return SFM_OK;
+}
+
 int ba_flow_setup(sfm_ba_problem* p) {
   BaDev& d = p->dev;
   if (d.nbk < 2 || d.nbk > kFlowMaxNbk) return SFM_OK;
   // field switch: SFM_FLOW_SOLVE=0 keeps every problem on the column-step launches (what SFM_OPT_DEBUG bit 1024 does per handle)
   static const bool enabled = [] { const char* e = getenv("SFM_FLOW_SOLVE"); return !(e && atoi(e) == 0); }();
   if (!enabled) return SFM_OK;
-  // The task table depends on nbk alone: one device copy per (device, nbk) for the life of the process, so that the per-view
-  // sfm_ba_append of the drop-in classes (a new problem object every time) neither allocates nor copies it again.
-  static std::mutex mu;
-  static std::map<long long, std::pair<void*, int>> tables;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    const long long key = (long long)ctx().device * 1000 + d.nbk;
-    auto it = tables.find(key);
-    if (it == tables.end()) {
-      const std::vector<FlowTask> tasks = flow_build_tasks(d.nbk);
-      void* tk = nullptr;
-      SFM_HIP(hipMalloc(&tk, sizeof(FlowTask) * std::max<size_t>(1, tasks.size())));
-      if (!tasks.empty()) SFM_HIP(hipMemcpy(tk, tasks.data(), sizeof(FlowTask) * tasks.size(), hipMemcpyHostToDevice));
-      it = tables.emplace(key, std::make_pair(tk, (int)tasks.size())).first;
-    }
-    d.flow_tasks = it->second.first;
-    d.flow_ntasks = it->second.second;
-  }
+  SFM_TRY(flow_task_table(d.nbk, d.nbk, 0, &d.flow_tasks, &d.flow_ntasks));
+  SFM_TRY(flow_task_table(1000 + d.V, d.nbk, d.V, &p->flow_tasks_red, &p->flow_ntasks_red));
   SFM_HIP(pool_alloc(reinterpret_cast<void**>(&d.flow), sizeof(unsigned) * flow_words(d.nbk)));
   SFM_HIP(hipMemsetAsync(d.flow, 0, sizeof(unsigned) * flow_words(d.nbk), p->stream));
+  SFM_HIP(pool_alloc(reinterpret_cast<void**>(&p->flow_camsum), sizeof(double) * 4 * 35 * (size_t)d.V));
   static int attr_device = -1;
   if (attr_device != ctx().device) {
     SFM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_flow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsBytes));
@@ -792,11 +798,36 @@ int ba_flow_setup(sfm_ba_problem* p) {
   return SFM_OK;
 }
 
+// which of the three solve paths ba_enqueue_reduced_solve takes
+static bool solve_uses_small(const BaDev& d) { return d.P <= ((d.debug & 256) ? kSmallMaxP : kSmallUseP) && !(d.debug & 64); }
+static bool solve_uses_flow(const BaDev& d) {
+  // the identity rows ride along (SFM_OPT_DEBUG bit 512: leave them out and back-substitute block row by block row);
+  // SFM_OPT_DEBUG bit 1024: column steps as separate launches where the data-flow launch would run
+  return !solve_uses_small(d) && !(d.debug & 512) && d.nbk <= kInvRowsMaxNbk && d.flow != nullptr && !(d.debug & 1024);
+}
+
+// The split-K reduce of the dense product can be left to the data-flow launch (FlowRed in sfm_ba_flow.h) when nothing but that launch
+// reads S: iterations enqueued by sfm_ba_iterate on one GPU (no all-reduce of [S | rhs] in between), per-workgroup camera accumulators
+// from ba_linearize, not the deterministic mode (which keeps its own summation order).  SFM_OPT_DEBUG bit 16384: never.
+bool ba_solve_can_defer_reduce(const sfm_ba_problem* p) {
+  const BaDev& d = p->dev;
+  if (!(solve_uses_flow(d) && p->flow_tasks_red != nullptr && p->flow_camsum != nullptr && !(d.debug & 16384) && !p->deterministic &&
+        p->comm == nullptr && p->lin_rows > 0)) return false;
+  // a task sums ALL slabs of its elements (one workgroup per 8 rows of a block): with few tiles (up to 36 cameras: one to three
+  // tiles share the 256 slabs) that is a long dependent chain of loads, and the reduce kernel's many short ones win
+  const SchurPlan pl = ba_schur_dense_plan(p);
+  int most = 0;
+  for (int c = 0; c < 4; ++c)
+    if (plan_tiles_in_class(pl, c) > 0) most = std::max(most, pl.chunks[c]);
+  return most <= 96;
+}
+
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   hipStream_t s = p->stream;
   const BaDev& d = p->dev;
   const int nbk = d.nbk;
-  if (d.P <= ((d.debug & 256) ? kSmallMaxP : kSmallUseP) && !(d.debug & 64)) {      // SFM_OPT_DEBUG bit 64: block steps for every size; 256: the small kernel up to P = 64
+  if (p->reduce_deferred && !solve_uses_flow(d)) return SFM_E_HIP;      // (ba_solve_can_defer_reduce said otherwise)
+  if (solve_uses_small(d)) {      // SFM_OPT_DEBUG bit 64: block steps for every size; 256: the small kernel up to P = 64
     ba_small_solve_kernel<<<1, SM_THREADS, 0, s>>>(d, p->cur, lambda);
     SFM_HIP(hipGetLastError());
     return SFM_OK;
@@ -806,12 +837,20 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
   // (tools/time_solve_paths.py) 153 vs 198 us at nbk = 20, 293 vs 340 at 35, 422 vs 448 at 44, 643 vs 640 at 57,
   // 932 vs 910 at 75 -- used up to 52 block columns (V <= 237)
   const bool with_inv = !(d.debug & 512) && nbk <= kInvRowsMaxNbk;
-  // SFM_OPT_DEBUG bit 1024: column steps as separate launches where the data-flow launch would run
-  if (with_inv && d.flow != nullptr && !(d.debug & 1024)) {
-    const int grid = 1 + std::min(d.flow_ntasks, ctx().num_cus - 32);
+  if (solve_uses_flow(d)) {
+    FlowRed fr{};
+    const FlowTask* tasks = static_cast<const FlowTask*>(d.flow_tasks);
+    int ntasks = d.flow_ntasks;
+    if (p->reduce_deferred) {
+      fr.ws = static_cast<const double*>(p->schur_ws); fr.camsum = p->flow_camsum; fr.plan = ba_schur_dense_plan(p);
+      fr.lin_rows = p->lin_rows; fr.lin_grid = p->lin_grid;
+      tasks = static_cast<const FlowTask*>(p->flow_tasks_red); ntasks = p->flow_ntasks_red;
+      p->reduce_deferred = false;
+    }
+    const int grid = 1 + std::min(ntasks, ctx().num_cus - 32);
     // SFM_OPT_DEBUG bit 2048: dp = X y and the camera update as their own launch behind the data-flow launch
     const bool fused_dp = !(d.debug & 2048);
-    ba_chol_flow_kernel<<<grid, 512, kFlowLdsBytes, s>>>(d, d.flow, static_cast<const FlowTask*>(d.flow_tasks), d.flow_ntasks, lambda, fused_dp ? p->cur : -1);
+    ba_chol_flow_kernel<<<grid, 512, kFlowLdsBytes, s>>>(d, d.flow, tasks, ntasks, lambda, fused_dp ? p->cur : -1, fr);
     if (!fused_dp) ba_inv_apply_kernel<<<nbk, IA_THREADS, 0, s>>>(d, p->cur);
     SFM_HIP(hipGetLastError());
     return SFM_OK;
@@ -858,6 +897,15 @@ int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
 
 // Diagnostic (CPU only, no device needed): the task table of the data-flow solve for nbk block columns, in the order the
 // workgroups take it -- int[4] per task: {type (0 block of L, 1 closer, 2 hand-over (i, i-1), 3 rhs, 4 identity row), row, column, key}.
+extern "C" int sfm_ba_flow_tasks_deferred(int n_cams, int* out, int capacity) {
+  const int nbk = (7 * n_cams + sfm::kNB - 1) / sfm::kNB;
+  if (n_cams < 1 || nbk < 2 || nbk > sfm::kFlowMaxNbk) return 0;
+  const std::vector<sfm::FlowTask> t = sfm::flow_build_tasks(nbk, n_cams);
+  if (out != nullptr)
+    for (size_t q = 0; q < t.size() && (int)q < capacity; ++q) { out[4 * q] = t[q].type; out[4 * q + 1] = t[q].i; out[4 * q + 2] = t[q].k; out[4 * q + 3] = t[q].key; }
+  return (int)t.size();
+}
+
 extern "C" int sfm_ba_flow_tasks(int nbk, int* out, int capacity) {
   if (nbk < 2 || nbk > sfm::kFlowMaxNbk) return 0;
   const std::vector<sfm::FlowTask> t = sfm::flow_build_tasks(nbk);

@@ -22,6 +22,7 @@ OPT_SCHUR, OPT_TIMING, OPT_DEBUG, OPT_DETERMINISTIC, OPT_GRAPH, OPT_TIMING_STRID
 K_PREP, K_LINEARIZE, K_SCHUR, K_SOLVE, K_BACKSUB, K_REDUCE, K_COUNT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = ("prep", "linearize", "schur", "solve", "backsub", "reduce")
 INFO_SCHUR_KERNEL, INFO_UPLOAD_BYTES, INFO_N_CAMS, INFO_N_PTS, INFO_N_OBS, INFO_MAX_TRACK, INFO_GRAPH_REPLAYS = 1, 2, 3, 4, 5, 6, 7
+INFO_REDUCE_IN_SOLVE = 8
 
 # every symbol include/sfm_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
@@ -40,7 +41,7 @@ EXPORTS = (
     "sfm_ba_bind_reduced_buffer", "sfm_ba_residual_jacobian", "sfm_ba_reduced_system",
     "sfm_pool_mode", "sfm_tri_nonlinear_dev", "sfm_tri_linear_dev", "sfm_triangulate_dev", "sfm_pnp_nonlinear_batch_dev",
     "sfm_gather_points_dev", "sfm_ba_points_ptr", "sfm_ba_stream", "sfm_ba_event_overhead",
-    "sfm_ba_get_state_rot", "sfm_ba_rederive_quaternions", "sfm_ba_flow_tasks",
+    "sfm_ba_get_state_rot", "sfm_ba_rederive_quaternions", "sfm_ba_flow_tasks", "sfm_ba_flow_tasks_deferred",
 )
 
 _lib = None
@@ -194,6 +195,18 @@ def flow_tasks(nbk):
     out = np.zeros((max(n, 1), 4), dtype=np.int32)
     if n > 0:
         lib.sfm_ba_flow_tasks(int(nbk), iptr(out), n)
+    return out[:n]
+
+
+def flow_tasks_deferred(n_cams):
+    """Task table of the data-flow solve for n_cams cameras when the split-K reduce rides in its launch (host only): rows
+    {type, row, column, key}; type 5 = camera sums (camera, part), 6 = rows 8q..8q+7 (q = key & 3) of block (row, column) of S."""
+    lib = load()
+    lib.sfm_ba_flow_tasks_deferred.argtypes = [ctypes.c_int, _ip, ctypes.c_int]
+    n = lib.sfm_ba_flow_tasks_deferred(int(n_cams), None, 0)
+    out = np.zeros((max(n, 1), 4), dtype=np.int32)
+    if n > 0:
+        lib.sfm_ba_flow_tasks_deferred(int(n_cams), iptr(out), n)
     return out[:n]
 
 

@@ -390,3 +390,41 @@ def test_flow_task_table_is_complete_and_dependency_ordered(sfm, nbk):
                 if m > i:
                     before(("X", i, m), n)
     assert sfm.native.flow_tasks(1).shape[0] == 0 and sfm.native.flow_tasks(53).shape[0] == 0
+
+
+@pytest.mark.parametrize("n_cams", [10, 14, 37, 50, 74, 120, 237])
+def test_flow_task_table_with_the_reduce_deferred_is_dependency_ordered(sfm, n_cams):
+    """sfm_ba_iterate on one GPU leaves the split-K reduce of the dense product to the data-flow launch: the table then starts with
+    one task per (camera, quarter of ba_linearize's accumulator rows) and one per 8 rows of every block of S but (0, 0), which the
+    chain sums itself.  Restated from the kernel's waits: rows of S on a camera's own 7x7 block need that camera's four sums; a
+    block of S is read by the chain (block rows 0-2), by the task of L[i][k] (k <= i-4), by the closer of row i (k = i-3, i-2, i)
+    or by its hand-over task (k = i-1); a block of y needs the sums of the cameras in its rows.  Every reader comes after what it
+    reads, and the rest of the table is the table of the plain solve in the same order."""
+    nbk = (7 * n_cams + 31) // 32
+    tab = sfm.native.flow_tasks_deferred(n_cams).tolist()
+    T1, CLOSER, H1, RHS, IDENT, CAMSUM, SRED, COST = range(8)
+    pos = {}
+    for n, (ty, i, k, key) in enumerate(tab):
+        name = {CAMSUM: ("cam", i, k), SRED: ("S", i, k, key & 3), COST: ("cost",)}.get(ty, (ty, i, k))
+        assert name not in pos
+        pos[name] = n
+    assert {x for x in pos if x[0] == "cam"} == {("cam", c, part) for c in range(n_cams) for part in range(4)}
+    assert {x for x in pos if x[0] == "S"} == {("S", i, k, q) for i in range(1, nbk) for k in range(i + 1) for q in range(4)}
+    assert ("cost",) in pos
+    plain = [r[:3] for r in sfm.native.flow_tasks(nbk).tolist()]
+    assert [r[:3] for r in tab if r[0] < CAMSUM] == plain
+    for n, (ty, i, k, key) in enumerate(tab):
+        if ty == SRED and k >= i - 1:
+            q = key & 3
+            for c in range((32 * i + 8 * q) // 7, min(n_cams - 1, (32 * i + 8 * q + 7) // 7) + 1):
+                for part in range(4):
+                    assert pos[("cam", c, part)] < n
+        reads = {T1: [(i, k)], H1: [(i, i - 1)], CLOSER: [(i, i - 3), (i, i - 2), (i, i)]}.get(ty, [])
+        for (a, b) in reads:
+            for q in range(4):
+                assert pos[("S", a, b, q)] < n
+        if ty == RHS:
+            for c in range((32 * k) // 7, min(7 * n_cams - 1, 32 * k + 31) // 7 + 1):
+                for part in range(4):
+                    assert pos[("cam", c, part)] < n
+    assert sfm.native.flow_tasks_deferred(4).shape[0] == 0 and sfm.native.flow_tasks_deferred(238).shape[0] == 0

@@ -530,6 +530,73 @@ def test_ba_data_flow_solves_on_four_streams_share_the_chip(hip, sfm):
             prob.close()
 
 
+@pytest.mark.parametrize("n_cams,n_pts,vis", [(37, 2500, 0.5), (50, 3000, 0.6), (73, 2500, 0.4), (120, 3000, 0.3), (234, 2500, 0.15)])
+def test_ba_reduce_inside_the_solve_launch_against_its_own_launch_and_oracle(hip, oracle, sfm, n_cams, n_pts, vis):
+    """sfm_ba_iterate on one GPU with the dense product leaves the split-K reduce to the first tasks of the data-flow launch
+    (camera sums per camera, 8 rows of a block of S per task, D_0 by the chain itself: csrc/sfm_ba_flow.h, FlowRed).  Against
+    SFM_OPT_DEBUG bit 16384 (ba_schur_reduce as its own launch) and the oracle, cameras, points and the per-iteration cost;
+    SFM_INFO_REDUCE_IN_SOLVE says which path ran; a second run and graph replays take the same path (1e-12: outside the
+    deterministic mode ba_linearize's LDS accumulation order varies from run to run)."""
+    sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=300 + n_cams)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 3)
+    res = {}
+    for name, dbg, graph in (("in the solve", 0, 0), ("again", 0, 0), ("own launch", 16384, 0), ("graph", 0, 1)):
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_option(hip.OPT_GRAPH, graph)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 3)
+            cams, pts = prob.get_state()
+            assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == (0 if dbg else 1)
+            if graph:      # the first iterations captured the two graphs (the camera slots alternate); the same again is replays
+                prob.set_state(sc.cams_init, sc.pts_init)
+                prob.iterate(5.0, 3)
+                again = prob.get_state()
+                assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 1
+                assert prob.info(hip.INFO_GRAPH_REPLAYS) >= (1 if n_cams <= 102 else 0)      # (graphs need the fused linearisation: up to 102 cameras)
+                assert rel(again[0], cams) < 1e-12 and rel(again[1], pts) < 1e-12
+            res[name] = (cams, pts, prob.get_stats()[:3].copy())
+    for name, (cams, pts, cost) in res.items():
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL, name
+        assert np.all(cost > 0) and rel(cost, res["own launch"][2]) < 1e-12, name
+    assert rel(res["in the solve"][0], res["again"][0]) < 1e-12 and rel(res["in the solve"][1], res["again"][1]) < 1e-12
+    assert rel(res["in the solve"][0], res["own launch"][0]) < 1e-11
+    assert rel(res["graph"][0], res["in the solve"][0]) < 1e-12
+
+
+def test_ba_reduce_stays_its_own_launch_where_the_solve_cannot_take_it(hip, oracle, sfm):
+    """Few tiles (up to 36 cameras: every task would sum 85-256 slabs), the sparse products, the deterministic mode, the
+    column-step solve, more than 234 cameras (ba_linearize then adds to S with global atomics: no per-workgroup sums to take) and the split entry points sfm_ba_linearize_reduce / sfm_ba_solve_update (whose caller all-reduces S in
+    between) keep ba_schur_reduce: SFM_INFO_REDUCE_IN_SOLVE reads 0 and the results are the oracle's."""
+    for n_cams, mode, dbg, det in ((20, "mfma", 0, 0), (50, "pairs", 0, 0), (50, "mfma", 1024, 0), (50, "mfma", 0, 1), (237, "mfma", 0, 0)):
+        sc = sfm.scenes.make_scene(n_cams, 1500, 0.5, seed=500 + n_cams)
+        uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+        want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+        with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+            prob.set_option(hip.OPT_SCHUR, {"mfma": hip.SCHUR_MFMA, "pairs": hip.SCHUR_PAIRS}[mode])
+            prob.set_option(hip.OPT_DEBUG, dbg)
+            prob.set_option(hip.OPT_DETERMINISTIC, det)
+            prob.set_state(sc.cams_init, sc.pts_init)
+            prob.iterate(5.0, 2)
+            cams, pts = prob.get_state()
+            assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 0
+        assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+    sc = sfm.scenes.make_scene(50, 1500, 0.5, seed=550)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+        prob.set_state(sc.cams_init, sc.pts_init)
+        for _ in range(2):
+            prob.linearize_reduce(5.0)
+            assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 0
+            prob.solve_update(5.0)
+        cams, pts = prob.get_state()
+    assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
+
+
 @pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
 def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
     """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;

@@ -41,7 +41,7 @@ scene_args = st.tuples(st.integers(2, 40), st.integers(1, 400), st.sampled_from(
 
 @settings(**SETTINGS)
 @given(args=scene_args, lam=st.sampled_from([0.5, 5.0, 50.0]), iters=st.integers(1, 4),
-       mode=st.sampled_from(["auto", "pairs", "mfma", "rows"]), debug=st.sampled_from([0, 16, 64, 256, 512, 1024]))
+       mode=st.sampled_from(["auto", "pairs", "mfma", "rows"]), debug=st.sampled_from([0, 16, 64, 256, 512, 1024, 16384]))
 def test_ba_random_scene_matches_oracle(hip, oracle, sfm, args, lam, iters, mode, debug):
     n_cams, n_pts, vis, seed = args
     trace("ba", args, lam, iters, mode, debug)

@@ -29,11 +29,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "stamps":
     for j in range(10):
         print("prep %2d (rel. to step start): seen %6d  regs->LDS %6d  sync %6d  d'+trsm %6d  sync %6d  done %6d" % (
             j, pr[j, 5] - el[j, 0], pd[j, 0] - el[j, 0], pd[j, 1] - el[j, 0], pd[j, 3] - el[j, 0], pd[j, 4] - el[j, 0], pr[j, 6] - el[j, 0]))
-    print("chain total ticks", el[10, 2] - t0)
+    print("chain total ticks", el[10, 2] - t0, " kernel entry -> D_0 in LDS, first step starts:", t0 - el[0, 5])
     rt = raw[896:1024].reshape(16, 8)      # chain, constant 100 MHz clock (s_memrealtime): [0] step start, [1] preparation starts, [2] row in LDS, [3] W_j announced, [4] L[j+1][j] announced
     cl = raw[640:768].reshape(16, 8)       # closer of row i, same clock: [0] start, [6] last term of the sums there, [1] sums done, [5] W seen, [2] L[i-2][k] seen, [3] L formed, [4] hand-over announced
     t1 = raw[128:256].reshape(16, 8)       # task L[i][i-4], same clock: [0] start, [1] sum done, [2] W seen, [3] announced
     r0 = rt[0, 0]
+    if t1[0, 0]:      # deferred reduce: the way to D_0 (us since the chain workgroup's entry)
+        k0 = el[0, 6]; u0 = lambda v: (int(v) - int(k0)) / 100.0
+        print("deferred reduce, us since the chain's kernel entry: camera sums (0, part 0) start %.2f, rows summed %.2f, published %.2f | S(1,0) rows 0-7: start %.2f, slabs summed %.2f, camera sums seen %.2f, published %.2f | chain: D_0's slabs summed %.2f, camera sums seen %.2f, D_0 in LDS (thread 0) %.2f, first step starts %.2f" % (
+            u0(t1[0, 0]), u0(t1[0, 1]), u0(t1[0, 2]), u0(t1[1, 0]), u0(t1[1, 1]), u0(t1[1, 2]), u0(t1[1, 3]), u0(el[0, 7]), u0(el[1, 5]), u0(el[1, 6]), u0(r0)))
     us = lambda v: (int(v) - int(r0)) / 100.0
     print("cross-workgroup timeline, us on the 100 MHz clock since the chain's first step")
     for i in range(4, 11):
@@ -50,11 +54,13 @@ for (V, N, vis, seed) in ((9, 300, 0.8, 1), (10, 400, 0.6, 2), (14, 500, 0.5, 3)
     t0 = time.time()
     c_new, p_new = run(sc, uvn, 0, 2)
     c_old, p_old = run(sc, uvn, 1024, 2)
+    c_own, p_own = run(sc, uvn, 16384, 2)      # the reduce as its own launch
+    c_dense, _ = run(sc, uvn, 0, 2) if V > 140 else (c_new, None)
     oc, op = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, 5.0, 2)
-    r_old = float(np.max(np.abs(c_new - c_old)) / np.max(np.abs(c_old)))
+    r_old = max(float(np.max(np.abs(c_new - c_old)) / np.max(np.abs(c_old))), float(np.max(np.abs(c_new - c_own)) / np.max(np.abs(c_own))))
     r_or = float(np.max(np.abs(c_new - oc)) / np.max(np.abs(oc)))
     r_pt = float(np.max(np.abs(p_new - op)) / np.max(np.abs(op)))
     worst = max(worst, r_or, r_pt)
-    print("V=%d nbk=%d: flow vs column steps %.2e, vs oracle cams %.2e pts %.2e  (%.1f s)" % (V, (7 * V + 31) // 32, r_old, r_or, r_pt, time.time() - t0), flush=True)
+    print("V=%d nbk=%d: flow vs column steps / own reduce launch %.2e, vs oracle cams %.2e pts %.2e  (%.1f s)" % (V, (7 * V + 31) // 32, r_old, r_or, r_pt, time.time() - t0), flush=True)
 print("worst", worst)
 sys.exit(0 if worst < 1e-9 else 1)

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 sfm = importlib.import_module("structure-from-motion_amd"); native = sfm.native; native.init(0)
 for name, args in (("demo 6x1260", (6, 1260, 1.0)), ("8x2000@0.7", (8, 2000, 0.7)), ("9x2000@0.8", (9, 2000, 0.8)), ("10x3000@0.6", (10, 3000, 0.6)), ("14x3000@0.5", (14, 3000, 0.5)), ("18x3000@0.4", (18, 3000, 0.4)), ("20x3000@0.3", (20, 3000, 0.3)), ("30x3000@0.3", (30, 3000, 0.3))):
     sc = sfm.scenes.make_scene(*args, seed=0); uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
-    for mode, dbg, graph in ((native.SCHUR_AUTO, 0, 0), (native.SCHUR_AUTO, 0, 1), (native.SCHUR_AUTO, 64, 0), (native.SCHUR_PAIRS, 0, 0), (native.SCHUR_MFMA, 0, 0), (native.SCHUR_ROWS, 0, 0)):
+    for mode, dbg, graph in ((native.SCHUR_AUTO, 0, 0), (native.SCHUR_AUTO, 16384, 0), (native.SCHUR_AUTO, 0, 1), (native.SCHUR_AUTO, 64, 0), (native.SCHUR_PAIRS, 0, 0), (native.SCHUR_MFMA, 0, 0), (native.SCHUR_ROWS, 0, 0)):
         with native.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
             prob.set_option(native.OPT_SCHUR, mode); prob.set_option(native.OPT_DEBUG, dbg); prob.set_option(native.OPT_GRAPH, graph)
             prob.set_state(sc.cams_init, sc.pts_init); prob.iterate(5.0, 3); native.synchronize()
