@@ -98,10 +98,10 @@ def steady_state_launches(n_cams, schur_kernel, fused, debug=0, reduce_in_solve=
     p = 7 * n_cams
     nbk = (p + 31) // 32
     launches = {"ba_linearize": 1, schur_kernel: 1}
-    if not reduce_in_solve:      # (sfm_ba_iterate on one GPU leaves the dense product's split-K reduce to the data-flow launch: SFM_INFO_REDUCE_IN_SOLVE)
-        launches["ba_schur_reduce"] = 1
     if schur_kernel == "ba_schur_rows":
-        launches["ba_schur_rows_reduce"] = 1
+        launches["ba_schur_rows_reduce"] = 1    # (also adds ba_linearize's camera accumulators and sums its cost)
+    elif not reduce_in_solve:      # (sfm_ba_iterate on one GPU leaves the dense product's split-K reduce to the data-flow launch: SFM_INFO_REDUCE_IN_SOLVE)
+        launches["ba_schur_reduce"] = 1
     if not fused:
         launches["ba_backsub"] = 1
     if p <= 56:

@@ -642,11 +642,8 @@ int ba_enqueue_schur(sfm_ba_problem* p, hipStream_t s, bool allow_defer) {
       return SFM_OK;
     }
   } else if (choice == SFM_SCHUR_ROWS) {
-    // row-panel sparse product; its own reduce, then the camera accumulators / cost below
+    // row-panel sparse product and its own reduce, which also adds the camera accumulators and sums the cost
     SFM_TRY(ba_rows_enqueue(p, s));
-    pl = make_pairs_plan(d);
-    const int cam_blocks = p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0;
-    ba_schur_reduce_kernel<<<dim3(cam_blocks + 1, 4), 256, 0, s>>>(d, ws, pl, 0, p->lin_rows, p->lin_grid);
     ba_tick(p, SFM_K_REDUCE, false, s);
     SFM_HIP(hipGetLastError());
     return SFM_OK;

@@ -143,10 +143,19 @@ __global__ __launch_bounds__(ROWS_THREADS) void ba_schur_rows_kernel(BaDev d, co
 
 // S(lower) -= sum over a group's chunk slabs.  Thread per (row of S, column): coalesced along the column.
 __global__ __launch_bounds__(256) void ba_schur_rows_reduce_kernel(BaDev d, const double* __restrict__ ws, const int* __restrict__ group_first,
-                                                                   int R, int tpr) {
-  const int row = blockIdx.y;                            // 0 .. 7V-1
+                                                                   int R, int tpr, int lin_rows, int lin_grid) {
+  const int row = blockIdx.y;                            // 0 .. 7V-1; beyond: the camera-side sums of ba_linearize and its cost
+  if (row >= d.P) {
+    // what ba_schur_reduce's extra blocks do, in this launch (the two reduces overlap instead of following each other): block e of
+    // 12 x cam_blocks sums slice (e / cam_blocks, blockIdx.z) of 12 x gridDim.z of the accumulator rows for 256 accumulators
+    const int cam_blocks = (d.V * 35 + 255) / 256;
+    const int e = (row - d.P) * gridDim.x + blockIdx.x;
+    if (lin_rows > 0 && e < 12 * cam_blocks) cam_reduce_slice(d, lin_rows, (e % cam_blocks) * 256 + threadIdx.x, (e / cam_blocks) * gridDim.z + blockIdx.z, 12 * gridDim.z);
+    else if (e == (lin_rows > 0 ? 12 * cam_blocks : 0) && blockIdx.z == 0 && threadIdx.x < 64) cost_reduce(d, lin_grid);
+    return;
+  }
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col > row || row >= d.P) return;
+  if (col > row) return;
   const int g = (row / 7) / R;
   const int r = row - 7 * g * R;
   const int first = group_first[g], last = group_first[g + 1];
@@ -244,8 +253,7 @@ int ba_rows_plan(sfm_ba_problem* p) {
   return SFM_OK;
 }
 
-// The product + its reduce (the camera accumulators of ba_linearize and the cost are added by the caller through
-// ba_schur_reduce with no tiles).
+// The product + its reduce; the same launch adds the camera accumulators of ba_linearize and sums its cost (extra block rows).
 int ba_rows_enqueue(sfm_ba_problem* p, hipStream_t s) {
   const BaDev& d = p->dev;
   const size_t lds = sizeof(double) * (size_t)7 * p->rows_R * p->rows_tpl;
@@ -253,9 +261,11 @@ int ba_rows_enqueue(sfm_ba_problem* p, hipStream_t s) {
   ba_schur_rows_kernel<<<p->rows_wgs, ROWS_THREADS, lds, s>>>(d, static_cast<const int4*>(p->cam_ent), static_cast<const RowsWg*>(p->rows_table),
                                                              static_cast<double*>(p->rows_ws), p->rows_R, p->rows_tpr, p->rows_tpl, p->rows_cp);
   ba_tick(p, SFM_K_SCHUR, false, s);
-  ba_tick(p, SFM_K_REDUCE, true, s);       // closed by the caller behind the camera-accumulator reduce
-  ba_schur_rows_reduce_kernel<<<dim3((d.P + 255) / 256, d.P, 4), 256, 0, s>>>(d, static_cast<const double*>(p->rows_ws), p->rows_first,
-                                                                          p->rows_R, p->rows_tpr);
+  ba_tick(p, SFM_K_REDUCE, true, s);       // closed by the caller
+  const int gx = (d.P + 255) / 256;
+  const int extra = (p->lin_rows > 0 ? 12 * ((d.V * 35 + 255) / 256) : 0) + 1;      // blocks of the camera-side sums + the cost
+  ba_schur_rows_reduce_kernel<<<dim3(gx, d.P + (extra + gx - 1) / gx, 4), 256, 0, s>>>(d, static_cast<const double*>(p->rows_ws), p->rows_first,
+                                                                                       p->rows_R, p->rows_tpr, p->lin_rows, p->lin_grid);
   SFM_HIP(hipGetLastError());
   return SFM_OK;
 }
