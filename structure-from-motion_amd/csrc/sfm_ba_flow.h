@@ -199,6 +199,19 @@ struct FlowWait {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return have;
   }
+  // n <= 64 consecutive flags, one per lane: all there
+  __device__ __forceinline__ void wait_run(int first, int n) {
+    if (dead) return;
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+      unsigned v = epoch;
+      if (lane < n) v = __hip_atomic_load(flow + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__ballot(v != epoch)) break;
+      if ((spins & 63) == 63 && (aborted() || spins > limit)) { give_up(); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 };
 __device__ __forceinline__ void flow_publish(unsigned* flow, int idx, unsigned epoch) {
   __hip_atomic_store(flow + idx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -230,7 +243,7 @@ struct FlowCtx {
 // the loads of all of them travel together afterwards)
 __device__ __forceinline__ void flow_wait_S(FlowCtx& c, int i, int k0, int k1) {
   if (!c.sred) return;
-  for (int n = 4 * (k1 - k0 + 1), f = flow_fs(c.nbk, i, k0, 0); n > 0; n -= 16, f += 16) (void)c.w.wait_terms(f, 0, 0, 1, min(16, n), min(16, n));
+  for (int n = 4 * (k1 - k0 + 1), f = flow_fs(c.nbk, i, k0, 0); n > 0; n -= 64, f += 64) c.w.wait_run(f, min(64, n));
 }
 // tile (sx, sy) of S_blk^T of block (i, k): as the reduce kernel left it (plain loads), or as this launch's SRED tasks published it
 __device__ __forceinline__ f64x4 flow_ld_S(const FlowCtx& c, int i, int k, int sx, int sy) {
@@ -243,7 +256,7 @@ __device__ __forceinline__ f64x4 flow_ld_S(const FlowCtx& c, int i, int k, int s
 }
 // every part of the camera sums of cameras c0 .. c1 is there
 __device__ __forceinline__ void flow_wait_cams(FlowCtx& c, int c0, int c1) {
-  for (int n = 4 * (c1 - c0 + 1), f = flow_fc(c.nbk, c0, 0); n > 0; n -= 16, f += 16) (void)c.w.wait_terms(f, 0, 0, 1, min(16, n), min(16, n));
+  for (int n = 4 * (c1 - c0 + 1), f = flow_fc(c.nbk, c0, 0); n > 0; n -= 64, f += 64) c.w.wait_run(f, min(64, n));
 }
 __device__ __forceinline__ double flow_camsum(const FlowCtx& c, int t) {      // element t of [V][35], parts added in order
   double u = 0;
