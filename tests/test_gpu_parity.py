@@ -566,6 +566,35 @@ def test_ba_reduce_inside_the_solve_launch_against_its_own_launch_and_oracle(hip
     assert rel(res["graph"][0], res["in the solve"][0]) < 1e-12
 
 
+def test_ba_reduce_inside_the_solve_launch_random_shapes(hip, oracle, sfm):
+    """Fourteen seeded random shapes between 37 and 200 cameras with the dense product forced (every camera count has its own
+    split of the slabs over the tiles, its own cameras straddling the 32-row blocks and its own ragged last block), random
+    visibility, damping and iteration count: the reduce inside the solve's launch against the oracle and against its own launch;
+    appended cameras and points (a new problem shape behind the same handle) take the path again."""
+    rng = np.random.default_rng(5150)
+    for case in range(14):
+        n_cams = int(rng.integers(37, 201))
+        n_pts = int(rng.integers(400, 2500))
+        vis = float(rng.uniform(max(0.08, 6.0 / n_cams), 0.8))
+        lam = float(rng.choice([0.5, 5.0, 50.0]))
+        iters = int(rng.integers(1, 4))
+        sc = sfm.scenes.make_scene(n_cams, n_pts, vis, seed=1200 + case)
+        uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+        want_c, want_p = oracle.ba_sparse(sc.cams_init, sc.pts_init, sc.cam_idx, sc.pt_idx, uvn, lam, iters)
+        got = []
+        for dbg in (0, 16384):
+            with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as prob:
+                prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+                prob.set_option(hip.OPT_DEBUG, dbg)
+                prob.set_state(sc.cams_init, sc.pts_init)
+                prob.iterate(lam, iters)
+                got.append(prob.get_state())
+                assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == (0 if dbg else 1), (case, n_cams)
+        info = (case, n_cams, n_pts, vis, lam, iters)
+        assert rel(got[0][0], want_c) < TOL and rel(got[0][1], want_p) < TOL, info
+        assert rel(got[0][0], got[1][0]) < 1e-11 and rel(got[0][1], got[1][1]) < 1e-11, info
+
+
 def test_ba_reduce_stays_its_own_launch_where_the_solve_cannot_take_it(hip, oracle, sfm):
     """Few tiles (up to 36 cameras: every task would sum 85-256 slabs), the sparse products, the deterministic mode, the
     column-step solve, more than 234 cameras (ba_linearize then adds to S with global atomics: no per-workgroup sums to take) and the split entry points sfm_ba_linearize_reduce / sfm_ba_solve_update (whose caller all-reduces S in
