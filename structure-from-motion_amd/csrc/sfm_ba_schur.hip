@@ -505,6 +505,17 @@ static SchurPlan make_plan(const BaDev& d) {
     if (plan_wgs(pl) <= ctx().num_cus) break;
     budget *= 1.01;
   }
+  // ONE tile (up to 18 cameras): it is not split into more than kSchurMaxChunks slabs even if CUs stay idle -- a workgroup's k loop is
+  // short against its prologue there (a slab of 16 rows is ~0.15 us of a 6-9 us kernel), while every slab is 128 KB more for the
+  // reduce to sum per element: 6 x 1 260 32.1 -> 29.3 us per iteration, 8 x 2 000 36.3 -> 34.6, 10 x 3 000 52.0 -> 51.3.  (With three tiles,
+  // 19-36 cameras, the same cap costs the product more than the reduce gains: 20 x 3 000 71.5 -> 74.6 us.)
+  if (pl.nblk == 1)
+    for (int c = 0; c < 4; ++c)
+      if (pl.chunks[c] > kSchurMaxChunks) {
+        const int slabs_per = (slabs + kSchurMaxChunks - 1) / kSchurMaxChunks;
+        pl.chunks[c] = (slabs + slabs_per - 1) / slabs_per;
+        pl.rpc[c] = slabs_per * KSL;
+      }
   return pl;
 }
 

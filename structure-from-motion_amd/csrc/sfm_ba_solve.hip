@@ -813,13 +813,14 @@ bool ba_solve_can_defer_reduce(const sfm_ba_problem* p) {
   const BaDev& d = p->dev;
   if (!(solve_uses_flow(d) && p->flow_tasks_red != nullptr && p->flow_camsum != nullptr && !(d.debug & 16384) && !p->deterministic &&
         p->comm == nullptr && p->lin_rows > 0)) return false;
-  // a task sums ALL slabs of its elements (one workgroup per 8 rows of a block): with few tiles (up to 36 cameras: one to three
-  // tiles share the 256 slabs) that is a long dependent chain of loads, and the reduce kernel's many short ones win
+  // a task sums ALL slabs of its elements (one workgroup per 8 rows of a block): with three tiles (19-36 cameras) a tile has up to 192
+  // slabs, a long dependent chain of loads, and the reduce kernel's many short ones win; with one tile (9-18 cameras, capped at 80
+  // slabs) the two paths measure within 1 us of each other (44.4 / 43.5 us at 9 x 2 000, 67.8 / 66.9 at 18 x 3 000: the own launch wins)
   const SchurPlan pl = ba_schur_dense_plan(p);
   int most = 0;
   for (int c = 0; c < 4; ++c)
     if (plan_tiles_in_class(pl, c) > 0) most = std::max(most, pl.chunks[c]);
-  return most <= 96;
+  return pl.nblk >= 3 && most <= 96;
 }
 
 int ba_enqueue_reduced_solve(sfm_ba_problem* p, double lambda) {
