@@ -12,7 +12,7 @@ namespace sfm {
 // the dense product cuts the rows of S into blocks of RB regardless of cameras.
 constexpr int kSchurCB = 18;
 constexpr int kSchurRB = 128;
-constexpr int kSchurMaxChunks = 80;   // split-K slabs of the dense product's tile when it is the only one (up to 18 cameras)
+constexpr int kSchurMaxChunks = 128;  // split-K slabs of the dense product's tile when it is the only one (up to 18 cameras)
 constexpr int kSchurKSL = 16;    // Z rows per LDS slab; the row count of Zd is padded to a multiple of it
 constexpr int kInvRowsMaxNbk = 52;  // block columns up to which the column steps carry the identity rows (X = L^-T; sfm_ba_solve.hip)
 constexpr int kLinGridPerCu = 3; // ba_linearize workgroups per CU (132 VGPRs -> 3 waves/SIMD; forcing 4 measured 10 % slower)

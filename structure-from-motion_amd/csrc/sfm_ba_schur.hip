@@ -505,14 +505,17 @@ static SchurPlan make_plan(const BaDev& d) {
     if (plan_wgs(pl) <= ctx().num_cus) break;
     budget *= 1.01;
   }
-  // ONE tile (up to 18 cameras): it is not split into more than kSchurMaxChunks slabs even if CUs stay idle -- a workgroup's k loop is
-  // short against its prologue there (a slab of 16 rows is ~0.15 us of a 6-9 us kernel), while every slab is 128 KB more for the
-  // reduce to sum per element: 6 x 1 260 32.1 -> 29.3 us per iteration, 8 x 2 000 36.3 -> 34.6, 10 x 3 000 52.0 -> 51.3.  (With three tiles,
-  // 19-36 cameras, the same cap costs the product more than the reduce gains: 20 x 3 000 71.5 -> 74.6 us.)
+  // ONE tile (up to 18 cameras): it is split into at most kSchurMaxChunks = 128 slabs, and a workgroup gets at least three slabs of 16 rows,
+  // even if CUs stay idle -- a workgroup's k loop is short against its prologue there (a slab is ~0.15 us of a 6-9 us kernel), while every
+  // slab is 128 KB more for the reduce to sum per element row.  Sweep of the cap (16 ... 256, profiles/r4/sweep_schur_chunks.txt), us per
+  // iteration at one per CU -> now: 6 x 1 260 32.2 -> 28.9, 8 x 2 000 36.4 -> 34.4, 10 x 3 000 51.9 -> 50.5, 14 x 3 000 63.1 -> 61.2, 18 x 3 000
+  // 68.4 -> 65.2.  (With three tiles, 19-36 cameras, a cap costs the product more than the reduce gains: 20 x 3 000 71.5 -> 74.6 us at 80.)
+  static const int cap_env = [] { const char* e = getenv("SFM_SCHUR_MAX_CHUNKS"); return e ? atoi(e) : 0; }();      // (the sweep)
+  const int cap = cap_env > 0 ? cap_env : std::max(1, std::min(kSchurMaxChunks, slabs / 3));
   if (pl.nblk == 1)
     for (int c = 0; c < 4; ++c)
-      if (pl.chunks[c] > kSchurMaxChunks) {
-        const int slabs_per = (slabs + kSchurMaxChunks - 1) / kSchurMaxChunks;
+      if (pl.chunks[c] > cap) {
+        const int slabs_per = (slabs + cap - 1) / cap;
         pl.chunks[c] = (slabs + slabs_per - 1) / slabs_per;
         pl.rpc[c] = slabs_per * KSL;
       }
