@@ -587,6 +587,8 @@ int sfm_ba_append(sfm_ba_problem* p, int n_new_cams, const double* cams_new, int
   std::swap(p->dev, q->dev);
   std::swap(p->own_red, q->own_red);
   std::swap(p->schur_ws, q->schur_ws);
+  std::swap(p->flow_tasks_red, q->flow_tasks_red); std::swap(p->flow_ntasks_red, q->flow_ntasks_red); std::swap(p->flow_camsum, q->flow_camsum);
+  p->reduce_deferred = false; p->last_reduce_deferred = false;
   std::swap(p->schur_blk_ptr, q->schur_blk_ptr);
   std::swap(p->schur_mfma_ok, q->schur_mfma_ok);
   std::swap(p->rows_built, q->rows_built); std::swap(p->rows_ok, q->rows_ok);

@@ -55,6 +55,35 @@ def test_append_equals_fresh_problem(hip, sfm, schur):
     assert sfm.scenes.reprojection_rmse(cams_c, pts_c, sc) < sfm.scenes.reprojection_rmse(cams_b, pts_b, sc)
 
 
+def test_append_keeps_the_reduce_inside_the_solve_launch(hip, sfm):
+    """A scene of 40 cameras grows to 46 behind the same handle (sfm_ba_append plans a new problem: other tiles, other tables):
+    the iterations before and after the growth leave the split-K reduce to the solve's launch (SFM_INFO_REDUCE_IN_SOLVE) and end
+    where a fresh problem of the grown scene ends."""
+    sc = sfm.scenes.make_scene(46, 1800, 0.5, seed=171)
+    uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)
+    v0, n0 = 40, 1500
+    keep, ptr0 = _subset(sc, v0, n0)
+    with hip.BaProblem(v0, ptr0, sc.cam_idx[keep], uvn[:, keep]) as prob:
+        prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+        prob.set_state(sc.cams_init[:v0], sc.pts_init[:, :n0])
+        prob.iterate(5.0, 2)
+        assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 1
+        new = np.flatnonzero(~keep)
+        prob.append(sc.cams_init[v0:], sc.pts_init[:, n0:], sc.cam_idx[new], sc.pt_idx[new], uvn[:, new])
+        cams_b, pts_b = prob.get_state()
+        prob.iterate(5.0, 2)
+        assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 1
+        cams_c, pts_c = prob.get_state()
+    with hip.BaProblem(sc.n_cams, sc.pt_ptr, sc.cam_idx, uvn) as fresh:
+        fresh.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+        fresh.set_option(hip.OPT_DEBUG, 16384)
+        fresh.set_state(cams_b, pts_b)
+        fresh.iterate(5.0, 2)
+        cams_f, pts_f = fresh.get_state()
+    assert np.max(np.abs(cams_c - cams_f)) <= 1e-11 * max(1.0, np.max(np.abs(cams_f)))
+    assert np.max(np.abs(pts_c - pts_f)) <= 1e-11 * max(1.0, np.max(np.abs(pts_f)))
+
+
 def test_append_rejects_bad_input(hip, sfm):
     sc = sfm.scenes.make_scene(3, 40, 1.0, seed=2)
     uvn = sfm.geometry.normalise_pixels(sc.uv_pix, sc.intrinsic)

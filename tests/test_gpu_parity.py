@@ -569,8 +569,8 @@ def test_ba_reduce_inside_the_solve_launch_against_its_own_launch_and_oracle(hip
 def test_ba_reduce_inside_the_solve_launch_random_shapes(hip, oracle, sfm):
     """Fourteen seeded random shapes between 37 and 200 cameras with the dense product forced (every camera count has its own
     split of the slabs over the tiles, its own cameras straddling the 32-row blocks and its own ragged last block), random
-    visibility, damping and iteration count: the reduce inside the solve's launch against the oracle and against its own launch;
-    appended cameras and points (a new problem shape behind the same handle) take the path again."""
+    visibility, damping and iteration count: the reduce inside the solve's launch against the oracle and against its own launch
+    (growth behind the same handle: tests/test_gpu_append.py)."""
     rng = np.random.default_rng(5150)
     for case in range(14):
         n_cams = int(rng.integers(37, 201))
