@@ -626,6 +626,40 @@ def test_ba_reduce_stays_its_own_launch_where_the_solve_cannot_take_it(hip, orac
     assert rel(cams, want_c) < TOL and rel(pts, want_p) < TOL
 
 
+def test_ba_reduce_inside_the_solve_launch_on_four_streams(hip, sfm):
+    """The same crowding with the split-K reduce inside the launches (dense product forced, default mode): 4 x 225 workgroups whose
+    first tasks are the reduce's meet 256 CUs; the chain is whichever workgroup of a launch arrives first, every task waits only for
+    the chain and for tasks taken before it.  Results as when the problems run alone (1e-11: the accumulation order inside
+    ba_linearize varies from run to run outside the deterministic mode)."""
+    import torch
+    sc = [sfm.scenes.make_scene(90, 1500, 0.3, seed=60 + q) for q in range(4)]
+    uv = [sfm.geometry.normalise_pixels(x.uv_pix, x.intrinsic) for x in sc]
+    alone = []
+    for x, u in zip(sc, uv):
+        with hip.BaProblem(x.n_cams, x.pt_ptr, x.cam_idx, u) as prob:
+            prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+            prob.set_state(x.cams_init, x.pts_init)
+            prob.iterate(5.0, 4)
+            alone.append(prob.get_state())
+            assert prob.info(hip.INFO_REDUCE_IN_SOLVE) == 1
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    probs = [hip.BaProblem(x.n_cams, x.pt_ptr, x.cam_idx, u) for x, u in zip(sc, uv)]
+    try:
+        for prob, st, x in zip(probs, streams, sc):
+            prob.set_option(hip.OPT_SCHUR, hip.SCHUR_MFMA)
+            prob.set_stream(st.cuda_stream)
+            prob.set_state(x.cams_init, x.pts_init)
+        for rep in range(4):
+            for prob in probs:
+                prob.iterate(5.0, 1)
+        for prob, want in zip(probs, alone):
+            cams, pts = prob.get_state()
+            assert rel(cams, want[0]) < 1e-11 and rel(pts, want[1]) < 1e-11
+    finally:
+        for prob in probs:
+            prob.close()
+
+
 @pytest.mark.parametrize("n_cams", [2, 3, 5, 6, 8, 9])
 def test_ba_small_system_kernel_against_block_steps_and_oracle(hip, oracle, sfm, n_cams):
     """P <= 56 (up to eight cameras; nine with SFM_OPT_DEBUG bit 256) solves in the single-launch whole-matrix kernel;
