@@ -36,7 +36,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
 
 
-scene_args = st.tuples(st.integers(2, 40), st.integers(1, 400), st.sampled_from([0.25, 0.5, 0.8, 1.0]), st.integers(0, 10_000))
+scene_args = st.tuples(st.integers(2, 64), st.integers(1, 400), st.sampled_from([0.25, 0.5, 0.8, 1.0]), st.integers(0, 10_000))
 
 
 @settings(**SETTINGS)
