@@ -26,6 +26,9 @@
 //                    the chain publishes later than W_i-3.
 //   tasks of the rhs row and of the identity rows e = 0 .. nbk-2: the same recurrence with their own blocks; the task that finishes
 //                    an identity row forms its part of dp = X y, the last one to arrive updates the cameras.
+//   with the split-K reduce riding in the launch (FlowRed, below): tasks ahead of all these sum ba_linearize's camera accumulators
+//                    (one camera, a quarter of the rows) and the product's slabs (8 rows of a block of S); the chain sums D_0 itself.
+//   Which workgroup is the chain is decided by arrival: the first to take a ticket; the others take tasks in table order.
 // Every block is produced by exactly one task with a fixed summation order: the result does not depend on timing or placement.
 // All products are formed TRANSPOSED (the 16x16x4 accumulator layout of M^T is the operand layout of M: rows lk + 4g), so a
 // block goes accumulator -> k-interleaved block (red_lblk_off) with two 16-byte stores per tile and comes back as an A or
@@ -130,11 +133,6 @@ __device__ __forceinline__ f64x4 ctile_ld_lds(const double* blk, int off) {
 __device__ __forceinline__ void ctile_st_sc1(FlowBuf b, size_t blk, int off, const f64x4& v) {
   st2_sc1(b, blk + off, f64x2{v[0], v[1]});
   st2_sc1(b, blk + off + 256, f64x2{v[2], v[3]});
-}
-// tile (sx, sy) of S_blk^T from a row-major block of S (plain loads: nothing in this launch writes S before its reader has it)
-__device__ __forceinline__ f64x4 ctile_ld_S(const double* blk, int sx, int sy, int lr, int lk) {
-  const double* p = blk + (16 * sy + lr) * kNB + 16 * sx + lk;
-  return f64x4{p[0], p[4], p[8], p[12]};
 }
 
 // Waiting.  Lane 0.. poll flags, lane 63 the abort word, relaxed agent-scope loads (sc1).  After a give-up (a sibling never
