@@ -364,7 +364,9 @@ int sfm_ba_flush(sfm_ba_problem* p);
  * sfm_ba_append / sfm_ba_destroy. */
 int sfm_ba_points_ptr(sfm_ba_problem* p, void** d_px, void** d_py, void** d_pz, int* n_pts);
 int sfm_ba_stream(sfm_ba_problem* p, void** hip_stream);
-/* DEVICE pointer + element count of the contiguous reduced buffer (doubles). */
+/* DEVICE pointer + element count of the contiguous reduced buffer (doubles).  It holds [S | rhs] between sfm_ba_linearize_reduce and
+ * sfm_ba_solve_update (what the caller all-reduces); the factorisation overwrites it, and sfm_ba_iterate on one GPU may never form S
+ * in it at all (SFM_INFO_REDUCE_IN_SOLVE) -- use sfm_ba_reduced_system to look at S. */
 int sfm_ba_reduced_buffer(sfm_ba_problem* p, void** device_ptr, int64_t* n_doubles, int* ld);
 /* Bind an externally owned DEVICE buffer (e.g. a torch tensor) as the reduced buffer. */
 int sfm_ba_bind_reduced_buffer(sfm_ba_problem* p, void* device_ptr, int64_t n_doubles);
